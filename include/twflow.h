@@ -1,0 +1,157 @@
+/*
+ * twflow.h — C ABI of libtwflow.so, the MI355X (gfx950) Farneback image-diff engine.
+ *
+ * This is the drop-in boundary for tidal-wave's hot path.  It replaces
+ *   - class OpticalFlow / OpticalFlowByCPU / OpticalFlowByGPU  (/root/reference/src/opticalflow.h:38-70,
+ *     src/opticalflow.cpp:78-119) — the Farneback flow of one expect/target pair, and
+ *   - the USE_GPU device selection and the span-grid threshold scan inside Consumer
+ *     (/root/reference/src/consumer.cpp:18-32 and :60-76).
+ * Everything is plain C: pointers and sizes, no C++/HIP/torch types.  No function throws or aborts
+ * ("Node-gyp cannot use exceptions", src/opticalflow.h:18): every call returns a tw_status.
+ *
+ * Threading: a tw_engine is NOT thread-safe; create one per worker thread (the reference creates one
+ * OpticalFlow per Consumer, src/consumer.cpp:27-35).  Different engines may be used concurrently from
+ * different threads.  tw_engine_create binds the HIP device on the calling thread; every later call
+ * re-binds it, so workers need not call hipSetDevice themselves (fixes the reference's main-thread
+ * cv::gpu::setDevice, src/consumer.cpp:22).
+ *
+ * There is no CPU fallback in this library: without a HIP device every compute entry point returns
+ * TW_E_DEVICE.
+ */
+#ifndef TWFLOW_H
+#define TWFLOW_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TWFLOW_ABI_VERSION 1
+
+/* Status codes.  The first four are enum ErrorCode of /root/reference/src/opticalflow.h:9-14. */
+typedef enum tw_status {
+    TW_OK = 0,
+    TW_E_BAD_PARAMETER = 1,    /* BadParameter   */
+    TW_E_BAD_IMAGE_FORMAT = 2, /* BadImageFormat */
+    TW_E_DONT_MATCH_SIZE = 3,  /* DontMatchSize  */
+    TW_E_DEVICE = 4,           /* HIP failure / no device; text via tw_last_error */
+    TW_E_NOMEM = 5,
+    TW_E_UNSUPPORTED = 6, /* e.g. pyrScale >= 1 (OpenCV asserts), polyN > 7 */
+    TW_E_BUSY = 7         /* all in-flight slots taken: tw_wait a ticket first */
+} tw_status;
+
+/* struct OpticalFlowParameter, /root/reference/src/opticalflow.h:28-36 (same fields, same order). */
+typedef struct tw_params {
+    double pyrScale;
+    int pyrLevels;
+    int winSize;
+    int pyrIterations;
+    int polyN;
+    double polySigma;
+    int flags; /* 256 = OPTFLOW_FARNEBACK_GAUSSIAN (default, src/broker.cpp:117); 0 = box window */
+} tw_params;
+
+/* struct Vector, /root/reference/src/message_queue.h:20-25. */
+typedef struct tw_vector {
+    int x;
+    int y;
+    double dx;
+    double dy;
+} tw_vector;
+
+typedef struct tw_engine tw_engine;
+typedef int64_t tw_ticket;
+
+/* Defaults of Broker::createInstance, /root/reference/src/broker.cpp:111-117. */
+void tw_default_params(tw_params* p);
+
+/* cv::gpu::getCudaEnabledDeviceCount() of src/consumer.cpp:19-20: number of usable HIP devices
+ * (0 when there is none or the runtime cannot initialise). */
+int tw_device_count(void);
+
+/* new OpticalFlowByGPU() + cv::gpu::setDevice(id), src/consumer.cpp:21-30.
+ * `slots` = image pairs that may be in flight at once on this engine (>= 1; each owns a HIP stream
+ * and a workspace).  Parameters are fixed per engine like Consumer::parameter (src/consumer.cpp:97). */
+tw_status tw_engine_create(int device, const tw_params* params, int slots, tw_engine** out);
+void tw_engine_destroy(tw_engine* e);
+
+/* Human-readable text for a status; the four reference codes have no fixed text of their own. */
+const char* tw_strerror(tw_status s);
+/* Message of the last failure on this engine (e.g. hipGetErrorString), "" if none. */
+const char* tw_last_error(const tw_engine* e);
+
+/* OpticalFlow::calculateInternal, /root/reference/src/opticalflow.h:49 / src/opticalflow.cpp:97-119:
+ * dense flow of one 8-bit gray pair (row stride in bytes), planar flowx/flowy out (w*h floats each,
+ * either may be NULL).  `seconds` = device compute time, the meaning of OpticalFlowStatus::time
+ * (src/opticalflow.cpp:112-118).  Both images must already have equal size (the <=5 px reconcile of
+ * src/opticalflow.cpp:52-68 is host-layer work). */
+tw_status tw_flow_u8(tw_engine* e, const uint8_t* expect, const uint8_t* target, int width, int height,
+                     ptrdiff_t stride, float* flowx, float* flowy, float* seconds);
+
+/* Flow + the span-grid scan of src/consumer.cpp:60-76 in one call; only the flagged grid vectors are
+ * copied back.  `out` has room for `cap` vectors; *n receives the number found (may exceed cap, then
+ * only cap are written).  Vectors are in the reference's row-major order (y, then x). */
+tw_status tw_diff_u8(tw_engine* e, const uint8_t* expect, const uint8_t* target, int width, int height,
+                     ptrdiff_t stride, int span, double threshold, tw_vector* out, int cap, int* n,
+                     float* seconds);
+
+/* Asynchronous pair of the same operation, for batching (the Manager queue keeps `slots` jobs in
+ * flight per GPU).  The host images are copied to pinned staging before tw_submit_u8 returns. */
+tw_status tw_submit_u8(tw_engine* e, const uint8_t* expect, const uint8_t* target, int width, int height,
+                       ptrdiff_t stride, int span, double threshold, tw_ticket* ticket);
+/* Same with the images already resident in device memory (HBM) of the engine's device. */
+tw_status tw_submit_dev(tw_engine* e, const void* d_expect, const void* d_target, int width, int height,
+                        ptrdiff_t stride, int span, double threshold, tw_ticket* ticket);
+tw_status tw_wait(tw_engine* e, tw_ticket ticket, tw_vector* out, int cap, int* n, float* seconds);
+
+/* Number of grid points ceil(h/span)*ceil(w/span): the capacity that can never overflow. */
+int tw_grid_capacity(int width, int height, int span);
+
+/* Raw device memory helpers so a host without a HIP binding can keep inputs resident. */
+tw_status tw_dev_alloc(tw_engine* e, size_t bytes, void** dptr);
+tw_status tw_dev_free(tw_engine* e, void* dptr);
+tw_status tw_dev_upload(tw_engine* e, void* dptr, const void* host, size_t bytes);
+
+/* ---- instrumentation (bench.py / tests) ---------------------------------------------------------- */
+
+/* Kernel classes, in data-flow order. */
+enum {
+    TW_K_PYR = 0,
+    TW_K_POLYEXP = 1,
+    TW_K_UPDATE_MATRICES = 2,
+    TW_K_BLUR_SOLVE = 3,
+    TW_K_SCAN = 4,
+    TW_K_COUNT = 5
+};
+
+/* Every later launch of kernel class `kclass` (-1: timing off) at pyramid level `level` (-1: every
+ * level) is bracketed by hipEvents on the stream it is launched on; totals accumulate until read. */
+tw_status tw_prof_select(tw_engine* e, int kclass, int level);
+/* Sum of event-measured milliseconds and number of launches since the last call; resets both. */
+tw_status tw_prof_read(tw_engine* e, double* ms_total, int* launches);
+/* Algorithmic bytes (SURVEY §8d model) of one launch of `kclass` at `level` for a w x h pair. */
+double tw_algorithmic_bytes(const tw_engine* e, int kclass, int level, int width, int height);
+/* Algorithmic bytes of one whole pair (sum over levels and stages, scan included). */
+double tw_algorithmic_bytes_pair(const tw_engine* e, int width, int height, int span);
+/* Number of pyramid levels (= index of the coarsest level) the engine uses for w x h. */
+int tw_num_levels(const tw_engine* e, int width, int height);
+
+/* ---- per-stage entry points (parity tests; host buffers, synchronous) --------------------------------
+ * Layouts: images/planes are dense row-major; R and M are 5 planes [5][h][w]; flow is 2 planes. */
+tw_status tw_stage_pyr_level(tw_engine* e, const uint8_t* img, int w0, int h0, int level, float* I, int* w,
+                             int* h);
+tw_status tw_stage_polyexp(tw_engine* e, const float* I, int w, int h, float* R5);
+tw_status tw_stage_update_matrices(tw_engine* e, const float* R0_5, const float* R1_5, const float* flow2,
+                                   int w, int h, float* M5);
+tw_status tw_stage_flow_upsample_update(tw_engine* e, const float* R0_5, const float* R1_5,
+                                        const float* prevflow2, int pw, int ph, int w, int h, float* flow2,
+                                        float* M5);
+tw_status tw_stage_blur_solve(tw_engine* e, const float* R0_5, const float* R1_5, const float* M5, int w, int h,
+                              int update_matrices, float* flow2, float* Mout5);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TWFLOW_H */

@@ -1,0 +1,80 @@
+"""The C-ABI library loads and exports every symbol include/*.h declares (no compute without a GPU)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    syms = set()
+    inc = os.path.join(ROOT, "include")
+    for fn in os.listdir(inc):
+        if fn.endswith(".h"):
+            txt = open(os.path.join(inc, fn)).read()
+            txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+            syms |= set(re.findall(r"\b(tw_[a-z0-9_]+)\s*\(", txt))
+    return syms
+
+
+def test_header_symbols_exported(twflow):
+    L = twflow.lib()
+    decl = declared_symbols()
+    assert len(decl) >= 20
+    for s in sorted(decl):
+        assert hasattr(L, s), "libtwflow.so does not export %s" % s
+    assert decl == set(twflow.SYMBOLS)
+
+
+def test_struct_layouts_match_reference(twflow):
+    # OpticalFlowParameter (src/opticalflow.h:28-36): double,int,int,int,int,double,int
+    assert C.sizeof(twflow.Params) == 40
+    assert twflow.Params.polySigma.offset == 24 and twflow.Params.flags.offset == 32
+    # Vector (src/message_queue.h:20-25): int,int,double,double
+    assert C.sizeof(twflow.Vector) == 24 and twflow.Vector.dx.offset == 8
+
+
+def test_defaults_are_broker_defaults(twflow):
+    p = twflow.default_params()  # src/broker.cpp:111-117
+    assert (p.pyrScale, p.pyrLevels, p.winSize, p.pyrIterations, p.polyN, p.polySigma, p.flags) == \
+        (0.5, 3, 30, 3, 7, 1.5, 256)
+
+
+def test_grid_capacity_and_strerror(twflow):
+    L = twflow.lib()
+    assert twflow.grid_capacity(1920, 1080, 10) == 108 * 192 == 20736
+    assert twflow.grid_capacity(180, 117, 10) == 12 * 18
+    assert twflow.grid_capacity(10, 10, 0) == 0
+    assert L.tw_strerror(3) == b"Don't match image size"  # src/opticalflow.cpp:54
+    assert L.tw_strerror(0) == b"OK"
+
+
+def test_no_device_means_error_not_fallback(twflow):
+    """Without a usable GPU the engine refuses to exist: there is no CPU path behind the ABI."""
+    if twflow.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(twflow.TwError) as ei:
+        twflow.Engine(0)
+    assert ei.value.code == twflow.TW_E_DEVICE
+
+
+def test_bad_params_rejected_before_touching_the_device(twflow):
+    L = twflow.lib()
+    h = C.c_void_p()
+    p = twflow.default_params(pyrScale=1.0)  # CV_Assert(pyr_scale < 1)
+    assert L.tw_engine_create(0, C.byref(p), 1, C.byref(h)) == twflow.TW_E_UNSUPPORTED
+    p = twflow.default_params(polyN=9)
+    assert L.tw_engine_create(0, C.byref(p), 1, C.byref(h)) == twflow.TW_E_UNSUPPORTED
+    assert not h.value
+
+
+def test_product_does_not_reference_oracle():
+    """The product path must not import, link or call anything under oracle/."""
+    pkg = os.path.join(ROOT, "tidal-wave_amd")
+    for dp, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".h", ".cpp", ".cc", ".js", "Makefile", ".gyp")):
+                txt = open(os.path.join(dp, fn), errors="ignore").read()
+                assert "oracle" not in txt.lower() or fn == "synth.py" and "CPU oracle" in txt, fn

@@ -1,0 +1,1248 @@
+// twflow.hip — engine + C ABI of libtwflow.so (see include/twflow.h).
+//
+// One tw_engine = one worker's view of one MI355X: `slots` independent in-flight image pairs, each with
+// its own HIP stream and device workspace (no allocation per job in steady state).  The host side only
+// builds the small per-level tables (Gaussian taps, bilinear coordinates, polynomial-expansion constants)
+// in double precision exactly as OpenCV 2.4.9 does on the CPU, and enqueues the kernels of
+// twflow_kernels.hip.h.  There is no CPU compute path in this library.
+#include "twflow_kernels.hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <float.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/twflow.h"
+
+using namespace twk;
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------
+// Host-side scalar helpers (OpenCV 2.4.9 semantics)
+// ---------------------------------------------------------------------------------------------------
+inline int cv_round(double v) { return (int)lrint(v); }  // cvtsd2si: round-half-even
+inline int cv_floor(double v)
+{
+    if (!(v > -2147483648.0 && v < 2147483648.0)) return INT32_MIN;
+    int i = (int)lrint(v);
+    return i - (v < (double)i);
+}
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// cv::getGaussianKernel(n, sigma, CV_32F) — imgproc/smooth.cpp
+void gaussian_kernel(int n, double sigma, std::vector<float>& k)
+{
+    static const float tab[4][7] = {{1.f},
+                                    {0.25f, 0.5f, 0.25f},
+                                    {0.0625f, 0.25f, 0.375f, 0.25f, 0.0625f},
+                                    {0.03125f, 0.109375f, 0.21875f, 0.28125f, 0.21875f, 0.109375f, 0.03125f}};
+    const float* fixed = (n % 2 == 1 && n <= 7 && sigma <= 0) ? tab[n >> 1] : nullptr;
+    k.resize(n);
+    const double sigmaX = sigma > 0 ? sigma : ((n - 1) * 0.5 - 1) * 0.3 + 0.8;
+    const double scale2X = -0.5 / (sigmaX * sigmaX);
+    double sum = 0;
+    for (int i = 0; i < n; i++) {
+        const double x = i - (n - 1) * 0.5;
+        const double t = fixed ? (double)fixed[i] : exp(scale2X * x * x);
+        k[i] = (float)t;
+        sum += k[i];
+    }
+    sum = 1. / sum;
+    for (int i = 0; i < n; i++) k[i] = (float)(k[i] * sum);
+}
+
+// Coordinate tables of cv::resize(INTER_LINEAR) for float data — imgproc/imgwarp.cpp
+struct ResizeTab {
+    std::vector<int> xofs, yofs;
+    std::vector<float> alpha, beta;
+    int xmax = 0;
+    int mode = 1;  // 0 same size, 1 linear, 2 area-fast 2x2
+};
+
+void make_resize_tab(int sw, int sh, int dw, int dh, ResizeTab& t)
+{
+    const double inv_scale_x = (double)dw / sw, inv_scale_y = (double)dh / sh;
+    const double scale_x = 1. / inv_scale_x, scale_y = 1. / inv_scale_y;
+    const int iscale_x = cv_round(scale_x), iscale_y = cv_round(scale_y);
+    const bool is_area_fast = fabs(scale_x - iscale_x) < DBL_EPSILON && fabs(scale_y - iscale_y) < DBL_EPSILON;
+    t.xofs.resize(dw);
+    t.yofs.resize(dh);
+    t.alpha.resize(2 * (size_t)dw);
+    t.beta.resize(2 * (size_t)dh);
+    t.xmax = dw;
+    if (sw == dw && sh == dh) {
+        // scale 1: fx = fy = 0 everywhere, the generic bilinear code copies exactly
+        t.mode = 0;
+        for (int x = 0; x < dw; x++) { t.xofs[x] = x; t.alpha[2 * x] = 1.f; t.alpha[2 * x + 1] = 0.f; }
+        for (int y = 0; y < dh; y++) { t.yofs[y] = y; t.beta[2 * y] = 1.f; t.beta[2 * y + 1] = 0.f; }
+        return;
+    }
+    if (is_area_fast && iscale_x == 2 && iscale_y == 2) {
+        // "INTER_AREA (fast) also is equal to INTER_LINEAR" branch: sum of the 2x2 block * 0.25f
+        t.mode = 2;
+        for (int x = 0; x < dw; x++) { t.xofs[x] = 2 * x; t.alpha[2 * x] = 0.5f; t.alpha[2 * x + 1] = 0.5f; }
+        for (int y = 0; y < dh; y++) { t.yofs[y] = 2 * y; t.beta[2 * y] = 0.5f; t.beta[2 * y + 1] = 0.5f; }
+        return;
+    }
+    t.mode = 1;
+    for (int dx = 0; dx < dw; dx++) {
+        float fx = (float)((dx + 0.5) * scale_x - 0.5);
+        int sx = cv_floor(fx);
+        fx -= sx;
+        if (sx < 0) { fx = 0; sx = 0; }
+        if (sx + 1 >= sw) {
+            if (dx < t.xmax) t.xmax = dx;
+            if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+        }
+        t.xofs[dx] = sx;
+        t.alpha[2 * dx] = 1.f - fx;
+        t.alpha[2 * dx + 1] = fx;
+    }
+    for (int dy = 0; dy < dh; dy++) {
+        float fy = (float)((dy + 0.5) * scale_y - 0.5);
+        int sy = cv_floor(fy);
+        fy -= sy;
+        t.yofs[dy] = sy;  // rows are clipped at use, weights are not (resizeGeneric_Invoker)
+        t.beta[2 * dy] = 1.f - fy;
+        t.beta[2 * dy + 1] = fy;
+    }
+}
+
+// FarnebackPolyExp constants — video/optflowgf.cpp; invG = G.inv(DECOMP_CHOLESKY) — core/lapack.cpp
+void polyexp_setup(int n, double sigma, PolyCoef& pc)
+{
+    std::vector<float> gb(2 * n + 1), xgb(2 * n + 1), xxgb(2 * n + 1);
+    float *g = gb.data() + n, *xg = xgb.data() + n, *xxg = xxgb.data() + n;
+    if (sigma < FLT_EPSILON) sigma = n * 0.3;
+    double s = 0.;
+    for (int x = -n; x <= n; x++) {
+        g[x] = (float)exp(-x * x / (2 * sigma * sigma));
+        s += g[x];
+    }
+    s = 1. / s;
+    for (int x = -n; x <= n; x++) {
+        g[x] = (float)(g[x] * s);
+        xg[x] = (float)(x * g[x]);
+        xxg[x] = (float)(x * x * g[x]);
+    }
+    double G[6][6] = {};
+    for (int y = -n; y <= n; y++)
+        for (int x = -n; x <= n; x++) {
+            G[0][0] += g[y] * g[x];
+            G[1][1] += g[y] * g[x] * x * x;
+            G[3][3] += g[y] * g[x] * x * x * x * x;
+            G[5][5] += g[y] * g[x] * x * x * y * y;
+        }
+    G[2][2] = G[0][3] = G[0][4] = G[3][0] = G[4][0] = G[1][1];
+    G[4][4] = G[3][3];
+    G[3][4] = G[4][3] = G[5][5];
+    double L[6][6], B[6][6] = {};
+    memcpy(L, G, sizeof(L));
+    for (int i = 0; i < 6; i++) B[i][i] = 1;
+    for (int i = 0; i < 6; i++) {
+        int j, k;
+        double t;
+        for (j = 0; j < i; j++) {
+            t = L[i][j];
+            for (k = 0; k < j; k++) t -= L[i][k] * L[j][k];
+            L[i][j] = t * L[j][j];
+        }
+        t = L[i][i];
+        for (k = 0; k < j; k++) {
+            const double u = L[i][k];
+            t -= u * u;
+        }
+        L[i][i] = 1. / sqrt(t);
+    }
+    for (int i = 0; i < 6; i++)
+        for (int j = 0; j < 6; j++) {
+            double t = B[i][j];
+            for (int k = 0; k < i; k++) t -= L[i][k] * B[k][j];
+            B[i][j] = t * L[i][i];
+        }
+    for (int i = 5; i >= 0; i--)
+        for (int j = 0; j < 6; j++) {
+            double t = B[i][j];
+            for (int k = 5; k > i; k--) t -= L[k][i] * B[k][j];
+            B[i][j] = t * L[i][i];
+        }
+    memset(&pc, 0, sizeof(pc));
+    for (int k = 0; k <= n && k < 8; k++) {
+        pc.g[k] = g[k];
+        pc.xg[k] = xg[k];
+        pc.xxg[k] = xxg[k];
+    }
+    pc.ig11 = B[1][1];
+    pc.ig03 = B[0][3];
+    pc.ig33 = B[3][3];
+    pc.ig55 = B[5][5];
+}
+
+// window taps of FarnebackUpdateFlow_GaussianBlur
+void window_kernel(int block_size, WinCoef& wc)
+{
+    const int m = block_size / 2;
+    const double sigma = m * 0.3;
+    double s = 1;
+    memset(&wc, 0, sizeof(wc));
+    wc.k[0] = (float)s;
+    for (int i = 1; i <= m; i++) {
+        const float t = (float)exp(-i * i / (2 * sigma * sigma));
+        wc.k[i] = t;
+        s += t * 2;
+    }
+    s = 1. / s;
+    for (int i = 0; i <= m; i++) wc.k[i] = (float)(wc.k[i] * s);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Plan: everything that depends only on (w0, h0, params)
+// ---------------------------------------------------------------------------------------------------
+struct LevelPlan {
+    int w = 0, h = 0, ld = 0;
+    long long ps = 0;  // plane stride (elements)
+    double sigma = 0, scale = 1;
+    int ksize = 3;
+    // pyramid tables (full-res -> level)
+    int *d_xofs = nullptr, *d_yofs = nullptr;
+    float *d_alpha = nullptr, *d_beta = nullptr, *d_kern = nullptr;
+    int mode = 1, xmax = 0, nrows_max = 0;
+    // flow upsample tables (level k+1 -> k)
+    int *d_uxofs = nullptr, *d_uyofs = nullptr;
+    float *d_ualpha = nullptr, *d_ubeta = nullptr;
+    int uxmax = 0;
+};
+
+struct Plan {
+    int w0 = 0, h0 = 0;
+    int levels = 0;  // index of the coarsest level
+    std::vector<LevelPlan> lv;
+    std::vector<void*> owned;  // device allocations
+};
+
+struct Slot {
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_done = nullptr;
+    // workspace
+    size_t cap_px = 0;  // ld0*h0 capacity
+    uint8_t* d_img = nullptr;
+    size_t img_cap = 0;
+    uint8_t* h_img = nullptr;  // pinned staging
+    float *I[2] = {nullptr, nullptr}, *R[2] = {nullptr, nullptr}, *M[2] = {nullptr, nullptr},
+          *flow[2] = {nullptr, nullptr};
+    int* d_count = nullptr;
+    ScanRec* d_rec = nullptr;
+    size_t rec_cap = 0;
+    int* h_count = nullptr;  // pinned: [0]=count, then ScanRec[HOST_RECS]
+    // state
+    bool busy = false;
+    int64_t gen = 0;
+    int w = 0, h = 0, span = 0;
+    int final_flow = 0;
+};
+
+constexpr int HOST_RECS = 1024;
+
+struct ProfPair {
+    hipEvent_t a, b;
+};
+
+}  // namespace
+
+struct tw_engine {
+    int device = 0;
+    tw_params p;
+    int nslots = 1;
+    std::vector<Slot> slots;
+    std::map<std::pair<int, int>, Plan*> plans;
+    PolyCoef pc;
+    WinCoef wc;
+    int win_m = 15;
+    std::string err;
+    int next_slot = 0;
+    // profiling
+    int prof_class = -1, prof_level = -1;
+    std::vector<ProfPair> prof_pending;
+    std::vector<hipEvent_t> prof_free;
+};
+
+namespace {
+
+#define TW_HIP(e, call)                                                                   \
+    do {                                                                                  \
+        hipError_t _err = (call);                                                         \
+        if (_err != hipSuccess) {                                                         \
+            (e)->err = std::string(#call) + ": " + hipGetErrorString(_err);               \
+            return _err == hipErrorOutOfMemory ? TW_E_NOMEM : TW_E_DEVICE;                \
+        }                                                                                 \
+    } while (0)
+
+template <typename T>
+tw_status upload_vec(tw_engine* e, Plan* pl, const std::vector<T>& v, T** out)
+{
+    void* d = nullptr;
+    TW_HIP(e, hipMalloc(&d, v.size() * sizeof(T) + 16));
+    pl->owned.push_back(d);
+    TW_HIP(e, hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    *out = (T*)d;
+    return TW_OK;
+}
+
+int plan_levels(int w0, int h0, double pyr_scale, int levels)
+{
+    const int min_size = 32;
+    int k;
+    double scale;
+    for (k = 0, scale = 1; k < levels; k++) {
+        scale *= pyr_scale;
+        if (w0 * scale < min_size || h0 * scale < min_size) break;
+    }
+    return k;
+}
+
+void level_geometry(int w0, int h0, double pyr_scale, int k, int* w, int* h, double* sigma, int* ksize,
+                    double* scale_out)
+{
+    double scale = 1;
+    for (int i = 0; i < k; i++) scale *= pyr_scale;
+    const double sg = (1. / scale - 1) * 0.5;
+    int smooth_sz = cv_round(sg * 5) | 1;
+    if (smooth_sz < 3) smooth_sz = 3;
+    *w = cv_round(w0 * scale);
+    *h = cv_round(h0 * scale);
+    *sigma = sg;
+    *ksize = smooth_sz;
+    *scale_out = scale;
+}
+
+int pyr_nrows_max(const ResizeTab& t, int h, int h0, int r)
+{
+    int mx = 0;
+    for (int y0 = 0; y0 < h; y0 += PYR_TH) {
+        const int yB = std::min(y0 + PYR_TH - 1, h - 1);
+        const int ylo = std::min(std::max(t.yofs[y0], 0), h0 - 1) - r;
+        const int yhi = std::min(std::max(t.yofs[yB] + 1, 0), h0 - 1) + r;
+        mx = std::max(mx, yhi - ylo + 1);
+    }
+    return mx;
+}
+
+tw_status get_plan(tw_engine* e, int w0, int h0, Plan** out)
+{
+    auto key = std::make_pair(w0, h0);
+    auto it = e->plans.find(key);
+    if (it != e->plans.end()) {
+        *out = it->second;
+        return TW_OK;
+    }
+    Plan* pl = new Plan();
+    pl->w0 = w0;
+    pl->h0 = h0;
+    const int req = std::min(std::max(e->p.pyrLevels, 0), 60);
+    pl->levels = plan_levels(w0, h0, e->p.pyrScale, req);
+    pl->lv.resize(pl->levels + 1);
+    for (int k = 0; k <= pl->levels; k++) {
+        LevelPlan& L = pl->lv[k];
+        level_geometry(w0, h0, e->p.pyrScale, k, &L.w, &L.h, &L.sigma, &L.ksize, &L.scale);
+        if (L.w < 1 || L.h < 1 || L.ksize > PYR_MAXK - 1) {
+            e->err = "pyramid level degenerate or smoothing kernel too large";
+            delete pl;
+            return TW_E_UNSUPPORTED;
+        }
+        L.ld = round_up(L.w, 32);
+        L.ps = (long long)L.ld * L.h;
+    }
+    for (int k = 0; k <= pl->levels; k++) {
+        LevelPlan& L = pl->lv[k];
+        ResizeTab t;
+        make_resize_tab(w0, h0, L.w, L.h, t);
+        std::vector<float> kern;
+        gaussian_kernel(L.ksize, L.sigma, kern);
+        L.mode = t.mode;
+        L.xmax = t.xmax;
+        L.nrows_max = pyr_nrows_max(t, L.h, h0, L.ksize / 2);
+        const size_t lds = (size_t)(PYR_MAXK + (size_t)L.nrows_max * (t.mode == 0 ? PYR_TW : 2 * PYR_TW)) * 4;
+        if (lds > 160 * 1024) {
+            e->err = "pyramid tile does not fit LDS (scale/kernel too large)";
+            for (void* d : pl->owned) (void)hipFree(d);
+            delete pl;
+            return TW_E_UNSUPPORTED;
+        }
+        tw_status s;
+        if ((s = upload_vec(e, pl, t.xofs, &L.d_xofs)) || (s = upload_vec(e, pl, t.yofs, &L.d_yofs)) ||
+            (s = upload_vec(e, pl, t.alpha, &L.d_alpha)) || (s = upload_vec(e, pl, t.beta, &L.d_beta)) ||
+            (s = upload_vec(e, pl, kern, &L.d_kern)))
+            return s;
+        if (k < pl->levels) {
+            const LevelPlan& P = pl->lv[k + 1];
+            ResizeTab u;
+            make_resize_tab(P.w, P.h, L.w, L.h, u);
+            if (u.mode == 2) {
+                // cannot happen for pyr_scale < 1 (the previous level is never twice as large)
+                e->err = "unexpected area-fast flow resize";
+                return TW_E_UNSUPPORTED;
+            }
+            L.uxmax = u.xmax;
+            if ((s = upload_vec(e, pl, u.xofs, &L.d_uxofs)) || (s = upload_vec(e, pl, u.yofs, &L.d_uyofs)) ||
+                (s = upload_vec(e, pl, u.alpha, &L.d_ualpha)) || (s = upload_vec(e, pl, u.beta, &L.d_ubeta)))
+                return s;
+        }
+    }
+    e->plans[key] = pl;
+    *out = pl;
+    return TW_OK;
+}
+
+tw_status slot_reserve(tw_engine* e, Slot& s, const Plan* pl, int span, bool need_img)
+{
+    const LevelPlan& L0 = pl->lv[0];
+    size_t px = (size_t)L0.ps;
+    for (const LevelPlan& L : pl->lv) px = std::max(px, (size_t)L.ps);
+    if (px > s.cap_px) {
+        for (int i = 0; i < 2; i++) {
+            if (s.I[i]) (void)hipFree(s.I[i]);
+            if (s.R[i]) (void)hipFree(s.R[i]);
+            if (s.M[i]) (void)hipFree(s.M[i]);
+            if (s.flow[i]) (void)hipFree(s.flow[i]);
+            s.I[i] = s.R[i] = s.M[i] = s.flow[i] = nullptr;
+        }
+        s.cap_px = 0;
+        for (int i = 0; i < 2; i++) {
+            TW_HIP(e, hipMalloc((void**)&s.I[i], px * 4 + 256));
+            TW_HIP(e, hipMalloc((void**)&s.R[i], px * 5 * 4 + 256));
+            TW_HIP(e, hipMalloc((void**)&s.M[i], px * 5 * 4 + 256));
+            TW_HIP(e, hipMalloc((void**)&s.flow[i], px * 2 * 4 + 256));
+        }
+        s.cap_px = px;
+    }
+    const size_t img = (size_t)pl->w0 * pl->h0 * 2;
+    if (need_img && img > s.img_cap) {
+        if (s.d_img) (void)hipFree(s.d_img);
+        if (s.h_img) (void)hipHostFree(s.h_img);
+        s.d_img = nullptr;
+        s.h_img = nullptr;
+        s.img_cap = 0;
+        TW_HIP(e, hipMalloc((void**)&s.d_img, img + 256));
+        TW_HIP(e, hipHostMalloc((void**)&s.h_img, img, hipHostMallocDefault));
+        s.img_cap = img;
+    }
+    if (span > 0) {
+        const size_t G = (size_t)tw_grid_capacity(pl->w0, pl->h0, span);
+        if (G > s.rec_cap) {
+            if (s.d_rec) (void)hipFree(s.d_rec);
+            s.d_rec = nullptr;
+            s.rec_cap = 0;
+            TW_HIP(e, hipMalloc((void**)&s.d_rec, G * sizeof(ScanRec) + 256));
+            s.rec_cap = G;
+        }
+    }
+    return TW_OK;
+}
+
+// ---- profiling hooks -------------------------------------------------------------------------------
+hipEvent_t prof_event(tw_engine* e)
+{
+    if (!e->prof_free.empty()) {
+        hipEvent_t ev = e->prof_free.back();
+        e->prof_free.pop_back();
+        return ev;
+    }
+    hipEvent_t ev = nullptr;
+    (void)hipEventCreate(&ev);
+    return ev;
+}
+
+struct ProfScope {
+    tw_engine* e;
+    hipStream_t st;
+    bool on;
+    ProfPair pp;
+    ProfScope(tw_engine* e_, hipStream_t st_, int kclass, int level) : e(e_), st(st_)
+    {
+        on = (e->prof_class == kclass && (e->prof_level < 0 || e->prof_level == level));
+        if (on) {
+            pp.a = prof_event(e);
+            pp.b = prof_event(e);
+            (void)hipEventRecord(pp.a, st);
+        }
+    }
+    ~ProfScope()
+    {
+        if (on) {
+            (void)hipEventRecord(pp.b, st);
+            e->prof_pending.push_back(pp);
+        }
+    }
+};
+
+// ---- kernel launch helpers -------------------------------------------------------------------------
+void launch_pyr(tw_engine* e, hipStream_t st, const Plan* pl, int k, const uint8_t* img0, const uint8_t* img1,
+                long long stride, float* I0, float* I1, int nimg)
+{
+    const LevelPlan& L = pl->lv[k];
+    PyrArgs a;
+    a.src[0] = img0;
+    a.src[1] = img1;
+    a.dst[0] = I0;
+    a.dst[1] = I1;
+    a.stride = stride;
+    a.w0 = pl->w0;
+    a.h0 = pl->h0;
+    a.w = L.w;
+    a.h = L.h;
+    a.ld = L.ld;
+    a.xofs = L.d_xofs;
+    a.alpha = L.d_alpha;
+    a.yofs = L.d_yofs;
+    a.beta = L.d_beta;
+    a.kern = L.d_kern;
+    a.ksize = L.ksize;
+    a.mode = L.mode;
+    a.xmax = L.xmax;
+    a.nrows_max = L.nrows_max;
+    const int P = (L.mode == 0) ? PYR_TW : 2 * PYR_TW;
+    const size_t lds = (size_t)(PYR_MAXK + (size_t)L.nrows_max * P) * 4;
+    dim3 grid((L.w + PYR_TW - 1) / PYR_TW, (L.h + PYR_TH - 1) / PYR_TH, nimg);
+    ProfScope ps(e, st, TW_K_PYR, k);
+    hipLaunchKernelGGL(tw_pyr_level, grid, dim3(256), lds, st, a);
+}
+
+tw_status launch_polyexp(tw_engine* e, hipStream_t st, int w, int h, int ld, long long ps, const float* I0,
+                         const float* I1, float* R0, float* R1, int nimg, int level)
+{
+    PolyArgs a;
+    a.src[0] = I0;
+    a.src[1] = I1;
+    a.dst[0] = R0;
+    a.dst[1] = R1;
+    a.w = w;
+    a.h = h;
+    a.ld = ld;
+    a.ps = ps;
+    a.c = e->pc;
+    dim3 grid((w + PE_TW - 1) / PE_TW, (h + PE_TH - 1) / PE_TH, nimg);
+    ProfScope pscope(e, st, TW_K_POLYEXP, level);
+    switch (e->p.polyN) {
+        case 1: hipLaunchKernelGGL(tw_polyexp<1>, grid, dim3(256), 0, st, a); break;
+        case 2: hipLaunchKernelGGL(tw_polyexp<2>, grid, dim3(256), 0, st, a); break;
+        case 3: hipLaunchKernelGGL(tw_polyexp<3>, grid, dim3(256), 0, st, a); break;
+        case 4: hipLaunchKernelGGL(tw_polyexp<4>, grid, dim3(256), 0, st, a); break;
+        case 5: hipLaunchKernelGGL(tw_polyexp<5>, grid, dim3(256), 0, st, a); break;
+        case 6: hipLaunchKernelGGL(tw_polyexp<6>, grid, dim3(256), 0, st, a); break;
+        case 7: hipLaunchKernelGGL(tw_polyexp<7>, grid, dim3(256), 0, st, a); break;
+        default: e->err = "polyN must be 1..7"; return TW_E_UNSUPPORTED;
+    }
+    return TW_OK;
+}
+
+void launch_blur(tw_engine* e, hipStream_t st, int w, int h, int ld, long long ps, const float* Min, float* Mout,
+                 float* flow, const float* R0, const float* R1, int update, int level)
+{
+    BlurArgs a;
+    a.Min = Min;
+    a.Mout = Mout;
+    a.flow = flow;
+    a.R0 = R0;
+    a.R1 = R1;
+    a.w = w;
+    a.h = h;
+    a.ld = ld;
+    a.ps = ps;
+    a.fps = ps;
+    a.update = update;
+    a.m = e->win_m;
+    a.c = e->wc;
+    const int gy = (h + BS_TH - 1) / BS_TH;
+    ProfScope pscope(e, st, TW_K_BLUR_SOLVE, level);
+    if (e->win_m == 15) {
+        if (w > 480) {
+            constexpr int TW = 256 - 32;
+            hipLaunchKernelGGL((tw_blur_solve<15, 256, 16>), dim3((w + TW - 1) / TW, gy), dim3(256), 0, st, a);
+        } else {
+            constexpr int TW = 128 - 32;
+            hipLaunchKernelGGL((tw_blur_solve<15, 128, 16>), dim3((w + TW - 1) / TW, gy), dim3(128), 0, st, a);
+        }
+    } else if (e->win_m == 25) {
+        if (w > 480) {
+            constexpr int TW = 256 - 64;
+            hipLaunchKernelGGL((tw_blur_solve<25, 256, 32>), dim3((w + TW - 1) / TW, gy), dim3(256), 0, st, a);
+        } else {
+            constexpr int TW = 128 - 64;
+            hipLaunchKernelGGL((tw_blur_solve<25, 128, 32>), dim3((w + TW - 1) / TW, gy), dim3(128), 0, st, a);
+        }
+    } else {
+        const size_t lds = (size_t)5 * BS_TH * (64 + 2 * e->win_m) * 4;
+        hipLaunchKernelGGL(tw_blur_solve_generic, dim3((w + 63) / 64, gy), dim3(256), lds, st, a);
+    }
+}
+
+void launch_update(tw_engine* e, hipStream_t st, const Plan* pl, int k, const float* R0, const float* R1,
+                   float* flow, const float* prev, float* M)
+{
+    const LevelPlan& L = pl->lv[k];
+    UpdArgs a;
+    memset(&a, 0, sizeof(a));
+    a.R0 = R0;
+    a.R1 = R1;
+    a.flow = flow;
+    a.M = M;
+    a.w = L.w;
+    a.h = L.h;
+    a.ld = L.ld;
+    a.ps = L.ps;
+    a.fps = L.ps;
+    dim3 grid((L.w + 63) / 64, (L.h + 3) / 4);
+    ProfScope pscope(e, st, TW_K_UPDATE_MATRICES, k);
+    if (k < pl->levels) {
+        const LevelPlan& P = pl->lv[k + 1];
+        a.prev = prev;
+        a.pw = P.w;
+        a.ph = P.h;
+        a.pld = P.ld;
+        a.pfps = P.ps;
+        a.xofs = L.d_uxofs;
+        a.alpha = L.d_ualpha;
+        a.yofs = L.d_uyofs;
+        a.beta = L.d_ubeta;
+        a.xmax = L.uxmax;
+        a.scale = (float)(1. / e->p.pyrScale);
+        hipLaunchKernelGGL(tw_update_matrices<true>, grid, dim3(256), 0, st, a);
+    } else {
+        a.zero_flow = 1;
+        hipLaunchKernelGGL(tw_update_matrices<false>, grid, dim3(256), 0, st, a);
+    }
+}
+
+// Enqueue the whole pair on the slot's stream.  Returns the index of the flow buffer holding level 0.
+tw_status enqueue_pair(tw_engine* e, Slot& s, const Plan* pl, const uint8_t* d_a, const uint8_t* d_b,
+                       long long stride, int span, double threshold)
+{
+    hipStream_t st = s.stream;
+    TW_HIP(e, hipEventRecord(s.ev_start, st));
+    for (int k = pl->levels; k >= 0; k--) {
+        const LevelPlan& L = pl->lv[k];
+        float* flow_cur = s.flow[k & 1];
+        const float* flow_prev = s.flow[(k + 1) & 1];
+        launch_pyr(e, st, pl, k, d_a, d_b, stride, s.I[0], s.I[1], 2);
+        tw_status r = launch_polyexp(e, st, L.w, L.h, L.ld, L.ps, s.I[0], s.I[1], s.R[0], s.R[1], 2, k);
+        if (r) return r;
+        launch_update(e, st, pl, k, s.R[0], s.R[1], flow_cur, flow_prev, s.M[0]);
+        for (int i = 0; i < e->p.pyrIterations; i++)
+            launch_blur(e, st, L.w, L.h, L.ld, L.ps, s.M[i & 1], s.M[(i + 1) & 1], flow_cur, s.R[0], s.R[1],
+                        i < e->p.pyrIterations - 1, k);
+    }
+    s.final_flow = 0;
+    TW_HIP(e, hipEventRecord(s.ev_stop, st));
+    if (span > 0) {
+        const LevelPlan& L0 = pl->lv[0];
+        ScanArgs a;
+        a.flow = s.flow[0];
+        a.fps = L0.ps;
+        a.w = L0.w;
+        a.h = L0.h;
+        a.ld = L0.ld;
+        a.span = span;
+        a.gw = (L0.w + span - 1) / span;
+        a.gh = (L0.h + span - 1) / span;
+        a.thr2 = threshold * threshold;
+        a.count = s.d_count;
+        a.rec = s.d_rec;
+        {
+            ProfScope pscope(e, st, TW_K_SCAN, 0);
+            hipLaunchKernelGGL(tw_span_scan, dim3(1), dim3(1024), 0, st, a);
+        }
+        // count + the first HOST_RECS records; the rest (rare) is fetched in tw_wait
+        TW_HIP(e, hipMemcpyAsync(s.h_count, s.d_count, sizeof(int), hipMemcpyDeviceToHost, st));
+        const size_t n = std::min((size_t)HOST_RECS, s.rec_cap);
+        TW_HIP(e, hipMemcpyAsync(s.h_count + 4, s.d_rec, n * sizeof(ScanRec), hipMemcpyDeviceToHost, st));
+    }
+    TW_HIP(e, hipGetLastError());
+    TW_HIP(e, hipEventRecord(s.ev_done, st));
+    return TW_OK;
+}
+
+tw_status check_dims(tw_engine* e, int width, int height)
+{
+    if (width < 1 || height < 1 || width > 32768 || height > 32768) {
+        e->err = "bad image size";
+        return TW_E_BAD_PARAMETER;
+    }
+    return TW_OK;
+}
+
+tw_status submit_common(tw_engine* e, const uint8_t* h_a, const uint8_t* h_b, const void* d_a, const void* d_b,
+                        int width, int height, ptrdiff_t stride, int span, double threshold, tw_ticket* ticket)
+{
+    if (!e) return TW_E_BAD_PARAMETER;
+    e->err.clear();
+    tw_status r = check_dims(e, width, height);
+    if (r) return r;
+    if (span < 0 || stride < width || (!h_a && !d_a) || (!h_b && !d_b)) {
+        e->err = "bad argument";
+        return TW_E_BAD_PARAMETER;
+    }
+    TW_HIP(e, hipSetDevice(e->device));
+    int si = -1;
+    for (int i = 0; i < e->nslots; i++) {
+        const int c = (e->next_slot + i) % e->nslots;
+        if (!e->slots[c].busy) {
+            si = c;
+            break;
+        }
+    }
+    if (si < 0) return TW_E_BUSY;
+    e->next_slot = (si + 1) % e->nslots;
+    Slot& s = e->slots[si];
+    Plan* pl = nullptr;
+    if ((r = get_plan(e, width, height, &pl))) return r;
+    if ((r = slot_reserve(e, s, pl, span, h_a != nullptr))) return r;
+    const uint8_t *da, *db;
+    long long dstride;
+    if (h_a) {
+        const size_t n = (size_t)width * height;
+        for (int y = 0; y < height; y++) {
+            memcpy(s.h_img + (size_t)y * width, h_a + (size_t)y * stride, width);
+            memcpy(s.h_img + n + (size_t)y * width, h_b + (size_t)y * stride, width);
+        }
+        TW_HIP(e, hipMemcpyAsync(s.d_img, s.h_img, 2 * n, hipMemcpyHostToDevice, s.stream));
+        da = s.d_img;
+        db = s.d_img + n;
+        dstride = width;
+    } else {
+        da = (const uint8_t*)d_a;
+        db = (const uint8_t*)d_b;
+        dstride = stride;
+    }
+    s.w = width;
+    s.h = height;
+    s.span = span;
+    if ((r = enqueue_pair(e, s, pl, da, db, dstride, span, threshold))) return r;
+    s.busy = true;
+    s.gen++;
+    if (ticket) *ticket = (tw_ticket)(s.gen * 1024 + si);
+    return TW_OK;
+}
+
+}  // namespace
+
+// =====================================================================================================
+// C ABI
+// =====================================================================================================
+extern "C" {
+
+void tw_default_params(tw_params* p)
+{
+    if (!p) return;
+    p->pyrScale = 0.5;
+    p->pyrLevels = 3;
+    p->winSize = 30;
+    p->pyrIterations = 3;
+    p->polyN = 7;
+    p->polySigma = 1.5;
+    p->flags = 256;
+}
+
+int tw_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char* tw_strerror(tw_status s)
+{
+    switch (s) {
+        case TW_OK: return "OK";
+        case TW_E_BAD_PARAMETER: return "BadParameter";
+        case TW_E_BAD_IMAGE_FORMAT: return "BadImageFormat";
+        case TW_E_DONT_MATCH_SIZE: return "Don't match image size";
+        case TW_E_DEVICE: return "HIP device error";
+        case TW_E_NOMEM: return "out of device memory";
+        case TW_E_UNSUPPORTED: return "unsupported parameter";
+        case TW_E_BUSY: return "all slots busy";
+    }
+    return "unknown";
+}
+
+const char* tw_last_error(const tw_engine* e) { return e ? e->err.c_str() : ""; }
+
+int tw_grid_capacity(int width, int height, int span)
+{
+    if (span <= 0 || width <= 0 || height <= 0) return 0;
+    return ((height + span - 1) / span) * ((width + span - 1) / span);
+}
+
+tw_status tw_engine_create(int device, const tw_params* params, int slots, tw_engine** out)
+{
+    if (!out) return TW_E_BAD_PARAMETER;
+    *out = nullptr;
+    tw_params p;
+    if (params) p = *params;
+    else tw_default_params(&p);
+    if (!(p.pyrScale < 1) || !(p.pyrScale > 0)) return TW_E_UNSUPPORTED;  // CV_Assert(pyr_scale < 1)
+    if (p.polyN < 1 || p.polyN > 7) return TW_E_UNSUPPORTED;
+    if (p.winSize < 2 || p.winSize / 2 > 32) return TW_E_UNSUPPORTED;
+    if (!(p.flags & 256)) return TW_E_UNSUPPORTED;  // box window: not built yet
+    if (p.pyrIterations < 0 || p.pyrLevels < 0) return TW_E_BAD_PARAMETER;
+    if (slots < 1) slots = 1;
+    if (slots > 64) slots = 64;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return TW_E_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return TW_E_DEVICE;
+    tw_engine* e = new tw_engine();
+    e->device = device;
+    e->p = p;
+    e->nslots = slots;
+    e->slots.resize(slots);
+    polyexp_setup(p.polyN, p.polySigma, e->pc);
+    window_kernel(p.winSize, e->wc);
+    e->win_m = p.winSize / 2;
+    for (Slot& s : e->slots) {
+        if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreate(&s.ev_start) != hipSuccess || hipEventCreate(&s.ev_stop) != hipSuccess ||
+            hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming) != hipSuccess ||
+            hipMalloc((void**)&s.d_count, 256) != hipSuccess ||
+            hipHostMalloc((void**)&s.h_count, 16 + HOST_RECS * sizeof(ScanRec), hipHostMallocDefault) != hipSuccess) {
+            tw_engine_destroy(e);
+            return TW_E_DEVICE;
+        }
+    }
+    *out = e;
+    return TW_OK;
+}
+
+void tw_engine_destroy(tw_engine* e)
+{
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    (void)hipDeviceSynchronize();
+    for (Slot& s : e->slots) {
+        for (int i = 0; i < 2; i++) {
+            if (s.I[i]) (void)hipFree(s.I[i]);
+            if (s.R[i]) (void)hipFree(s.R[i]);
+            if (s.M[i]) (void)hipFree(s.M[i]);
+            if (s.flow[i]) (void)hipFree(s.flow[i]);
+        }
+        if (s.d_img) (void)hipFree(s.d_img);
+        if (s.h_img) (void)hipHostFree(s.h_img);
+        if (s.d_count) (void)hipFree(s.d_count);
+        if (s.d_rec) (void)hipFree(s.d_rec);
+        if (s.h_count) (void)hipHostFree(s.h_count);
+        if (s.ev_start) (void)hipEventDestroy(s.ev_start);
+        if (s.ev_stop) (void)hipEventDestroy(s.ev_stop);
+        if (s.ev_done) (void)hipEventDestroy(s.ev_done);
+        if (s.stream) (void)hipStreamDestroy(s.stream);
+    }
+    for (auto& kv : e->plans) {
+        for (void* d : kv.second->owned) (void)hipFree(d);
+        delete kv.second;
+    }
+    for (ProfPair& pp : e->prof_pending) {
+        (void)hipEventDestroy(pp.a);
+        (void)hipEventDestroy(pp.b);
+    }
+    for (hipEvent_t ev : e->prof_free) (void)hipEventDestroy(ev);
+    delete e;
+}
+
+tw_status tw_submit_u8(tw_engine* e, const uint8_t* expect, const uint8_t* target, int width, int height,
+                       ptrdiff_t stride, int span, double threshold, tw_ticket* ticket)
+{
+    if (!expect || !target) return TW_E_BAD_PARAMETER;
+    return submit_common(e, expect, target, nullptr, nullptr, width, height, stride, span, threshold, ticket);
+}
+
+tw_status tw_submit_dev(tw_engine* e, const void* d_expect, const void* d_target, int width, int height,
+                        ptrdiff_t stride, int span, double threshold, tw_ticket* ticket)
+{
+    if (!d_expect || !d_target) return TW_E_BAD_PARAMETER;
+    return submit_common(e, nullptr, nullptr, d_expect, d_target, width, height, stride, span, threshold, ticket);
+}
+
+tw_status tw_wait(tw_engine* e, tw_ticket ticket, tw_vector* out, int cap, int* n, float* seconds)
+{
+    if (!e) return TW_E_BAD_PARAMETER;
+    const int si = (int)(ticket % 1024);
+    const int64_t gen = ticket / 1024;
+    if (si < 0 || si >= e->nslots || !e->slots[si].busy || e->slots[si].gen != gen) {
+        e->err = "unknown ticket";
+        return TW_E_BAD_PARAMETER;
+    }
+    Slot& s = e->slots[si];
+    TW_HIP(e, hipSetDevice(e->device));
+    hipError_t herr = hipEventSynchronize(s.ev_done);
+    s.busy = false;
+    if (herr != hipSuccess) {
+        e->err = std::string("hipEventSynchronize: ") + hipGetErrorString(herr);
+        return TW_E_DEVICE;
+    }
+    if (seconds) {
+        float ms = 0.f;
+        TW_HIP(e, hipEventElapsedTime(&ms, s.ev_start, s.ev_stop));
+        *seconds = ms * 1e-3f;
+    }
+    if (s.span > 0) {
+        const int cnt = s.h_count[0];
+        if (n) *n = cnt;
+        const int want = std::min(cnt, cap);
+        const ScanRec* hr = (const ScanRec*)(s.h_count + 4);
+        std::vector<ScanRec> extra;
+        if (want > HOST_RECS) {
+            extra.resize(want);
+            TW_HIP(e, hipMemcpy(extra.data(), s.d_rec, (size_t)want * sizeof(ScanRec), hipMemcpyDeviceToHost));
+            hr = extra.data();
+        }
+        if (out)
+            for (int i = 0; i < want; i++) {
+                out[i].x = hr[i].x;
+                out[i].y = hr[i].y;
+                out[i].dx = hr[i].dx;  // float widened to double, src/consumer.cpp:72-73
+                out[i].dy = hr[i].dy;
+            }
+    } else if (n) {
+        *n = 0;
+    }
+    return TW_OK;
+}
+
+tw_status tw_diff_u8(tw_engine* e, const uint8_t* expect, const uint8_t* target, int width, int height,
+                     ptrdiff_t stride, int span, double threshold, tw_vector* out, int cap, int* n, float* seconds)
+{
+    if (span < 1) return TW_E_BAD_PARAMETER;
+    tw_ticket t;
+    tw_status r = tw_submit_u8(e, expect, target, width, height, stride, span, threshold, &t);
+    if (r) return r;
+    return tw_wait(e, t, out, cap, n, seconds);
+}
+
+tw_status tw_flow_u8(tw_engine* e, const uint8_t* expect, const uint8_t* target, int width, int height,
+                     ptrdiff_t stride, float* flowx, float* flowy, float* seconds)
+{
+    tw_ticket t;
+    tw_status r = tw_submit_u8(e, expect, target, width, height, stride, 0, 0.0, &t);
+    if (r) return r;
+    const int si = (int)(t % 1024);
+    r = tw_wait(e, t, nullptr, 0, nullptr, seconds);
+    if (r) return r;
+    Slot& s = e->slots[si];
+    Plan* pl = nullptr;
+    if ((r = get_plan(e, width, height, &pl))) return r;
+    const LevelPlan& L0 = pl->lv[0];
+    const float* f = s.flow[s.final_flow];
+    if (flowx)
+        TW_HIP(e, hipMemcpy2D(flowx, (size_t)width * 4, f, (size_t)L0.ld * 4, (size_t)width * 4, height,
+                              hipMemcpyDeviceToHost));
+    if (flowy)
+        TW_HIP(e, hipMemcpy2D(flowy, (size_t)width * 4, f + L0.ps, (size_t)L0.ld * 4, (size_t)width * 4, height,
+                              hipMemcpyDeviceToHost));
+    return TW_OK;
+}
+
+tw_status tw_dev_alloc(tw_engine* e, size_t bytes, void** dptr)
+{
+    if (!e || !dptr) return TW_E_BAD_PARAMETER;
+    TW_HIP(e, hipSetDevice(e->device));
+    TW_HIP(e, hipMalloc(dptr, bytes));
+    return TW_OK;
+}
+tw_status tw_dev_free(tw_engine* e, void* dptr)
+{
+    if (!e) return TW_E_BAD_PARAMETER;
+    TW_HIP(e, hipSetDevice(e->device));
+    TW_HIP(e, hipFree(dptr));
+    return TW_OK;
+}
+tw_status tw_dev_upload(tw_engine* e, void* dptr, const void* host, size_t bytes)
+{
+    if (!e || !dptr || !host) return TW_E_BAD_PARAMETER;
+    TW_HIP(e, hipSetDevice(e->device));
+    TW_HIP(e, hipMemcpy(dptr, host, bytes, hipMemcpyHostToDevice));
+    return TW_OK;
+}
+
+// ---- instrumentation ---------------------------------------------------------------------------------
+tw_status tw_prof_select(tw_engine* e, int kclass, int level)
+{
+    if (!e || kclass >= TW_K_COUNT) return TW_E_BAD_PARAMETER;
+    e->prof_class = kclass;
+    e->prof_level = level;
+    return TW_OK;
+}
+
+tw_status tw_prof_read(tw_engine* e, double* ms_total, int* launches)
+{
+    if (!e) return TW_E_BAD_PARAMETER;
+    TW_HIP(e, hipSetDevice(e->device));
+    TW_HIP(e, hipDeviceSynchronize());
+    double tot = 0;
+    int cnt = 0;
+    for (ProfPair& pp : e->prof_pending) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, pp.a, pp.b) == hipSuccess) {
+            tot += ms;
+            cnt++;
+        }
+        e->prof_free.push_back(pp.a);
+        e->prof_free.push_back(pp.b);
+    }
+    e->prof_pending.clear();
+    if (ms_total) *ms_total = tot;
+    if (launches) *launches = cnt;
+    return TW_OK;
+}
+
+int tw_num_levels(const tw_engine* e, int width, int height)
+{
+    if (!e) return -1;
+    return plan_levels(width, height, e->p.pyrScale, std::min(std::max(e->p.pyrLevels, 0), 60));
+}
+
+double tw_algorithmic_bytes(const tw_engine* e, int kclass, int level, int width, int height)
+{
+    if (!e) return 0;
+    const int L = tw_num_levels(e, width, height);
+    if (level < 0 || level > L) return 0;
+    int w, h, ks;
+    double sg, sc;
+    level_geometry(width, height, e->p.pyrScale, level, &w, &h, &sg, &ks, &sc);
+    const double N = (double)w * h, N0 = (double)width * height;
+    const int it = e->p.pyrIterations;
+    switch (kclass) {
+        case TW_K_PYR: return 2 * (N0 + 4 * N);
+        case TW_K_POLYEXP: return 48 * N;  // 2 images x (4 + 20) B/px
+        case TW_K_UPDATE_MATRICES: {
+            double up = 8 * N;  // memset at the coarsest level
+            if (level < L) {
+                int pw, ph;
+                level_geometry(width, height, e->p.pyrScale, level + 1, &pw, &ph, &sg, &ks, &sc);
+                up = 8.0 * pw * ph + 8 * N;
+            }
+            return 68 * N + up;
+        }
+        case TW_K_BLUR_SOLVE:
+            // average over the `it` launches of a level: every launch blurs+solves (28N); all but the
+            // last also refresh M (68N) inside the same kernel
+            return it > 0 ? (it * 28 * N + (it - 1) * 68 * N) / it : 0;
+        default: return 0;
+    }
+}
+
+double tw_algorithmic_bytes_pair(const tw_engine* e, int width, int height, int span)
+{
+    if (!e) return 0;
+    const int L = tw_num_levels(e, width, height);
+    const int it = e->p.pyrIterations;
+    double tot = 0;
+    for (int k = 0; k <= L; k++) {
+        tot += tw_algorithmic_bytes(e, TW_K_PYR, k, width, height);
+        tot += tw_algorithmic_bytes(e, TW_K_POLYEXP, k, width, height);
+        tot += tw_algorithmic_bytes(e, TW_K_UPDATE_MATRICES, k, width, height);
+        tot += it * tw_algorithmic_bytes(e, TW_K_BLUR_SOLVE, k, width, height);
+    }
+    if (span > 0) tot += 16.0 * tw_grid_capacity(width, height, span);
+    return tot;
+}
+
+}  // extern "C"
+
+// ---- per-stage entry points (tests) --------------------------------------------------------------------
+namespace {
+struct Tmp {
+    std::vector<void*> v;
+    ~Tmp()
+    {
+        for (void* p : v) (void)hipFree(p);
+    }
+    template <typename T>
+    T* alloc(size_t n)
+    {
+        void* p = nullptr;
+        if (hipMalloc(&p, n * sizeof(T) + 256) != hipSuccess) return nullptr;
+        v.push_back(p);
+        return (T*)p;
+    }
+};
+tw_status up_planes(tw_engine* e, float* d, int ld, long long ps, const float* h, int w, int hh, int planes)
+{
+    for (int c = 0; c < planes; c++)
+        TW_HIP(e, hipMemcpy2D(d + c * ps, (size_t)ld * 4, h + (size_t)c * w * hh, (size_t)w * 4, (size_t)w * 4, hh,
+                              hipMemcpyHostToDevice));
+    return TW_OK;
+}
+tw_status down_planes(tw_engine* e, float* h, const float* d, int ld, long long ps, int w, int hh, int planes)
+{
+    for (int c = 0; c < planes; c++)
+        TW_HIP(e, hipMemcpy2D(h + (size_t)c * w * hh, (size_t)w * 4, d + c * ps, (size_t)ld * 4, (size_t)w * 4, hh,
+                              hipMemcpyDeviceToHost));
+    return TW_OK;
+}
+}  // namespace
+
+extern "C" {
+
+tw_status tw_stage_pyr_level(tw_engine* e, const uint8_t* img, int w0, int h0, int level, float* I, int* w, int* h)
+{
+    if (!e || !img || !I) return TW_E_BAD_PARAMETER;
+    TW_HIP(e, hipSetDevice(e->device));
+    Plan* pl = nullptr;
+    tw_status r = get_plan(e, w0, h0, &pl);
+    if (r) return r;
+    if (level < 0 || level > pl->levels) return TW_E_BAD_PARAMETER;
+    const LevelPlan& L = pl->lv[level];
+    Tmp t;
+    uint8_t* d_img = t.alloc<uint8_t>((size_t)w0 * h0);
+    float* d_I = t.alloc<float>((size_t)L.ps);
+    if (!d_img || !d_I) return TW_E_NOMEM;
+    TW_HIP(e, hipMemcpy(d_img, img, (size_t)w0 * h0, hipMemcpyHostToDevice));
+    hipStream_t st = e->slots[0].stream;
+    launch_pyr(e, st, pl, level, d_img, d_img, w0, d_I, d_I, 1);
+    TW_HIP(e, hipGetLastError());
+    TW_HIP(e, hipStreamSynchronize(st));
+    if ((r = down_planes(e, I, d_I, L.ld, L.ps, L.w, L.h, 1))) return r;
+    if (w) *w = L.w;
+    if (h) *h = L.h;
+    return TW_OK;
+}
+
+tw_status tw_stage_polyexp(tw_engine* e, const float* I, int w, int h, float* R5)
+{
+    if (!e || !I || !R5 || w < 1 || h < 1) return TW_E_BAD_PARAMETER;
+    TW_HIP(e, hipSetDevice(e->device));
+    const int ld = round_up(w, 32);
+    const long long ps = (long long)ld * h;
+    Tmp t;
+    float* d_I = t.alloc<float>((size_t)ps);
+    float* d_R = t.alloc<float>((size_t)ps * 5);
+    if (!d_I || !d_R) return TW_E_NOMEM;
+    tw_status r;
+    if ((r = up_planes(e, d_I, ld, ps, I, w, h, 1))) return r;
+    hipStream_t st = e->slots[0].stream;
+    if ((r = launch_polyexp(e, st, w, h, ld, ps, d_I, d_I, d_R, d_R, 1, -1))) return r;
+    TW_HIP(e, hipGetLastError());
+    TW_HIP(e, hipStreamSynchronize(st));
+    return down_planes(e, R5, d_R, ld, ps, w, h, 5);
+}
+
+tw_status tw_stage_update_matrices(tw_engine* e, const float* R0_5, const float* R1_5, const float* flow2, int w,
+                                   int h, float* M5)
+{
+    if (!e || !R0_5 || !R1_5 || !flow2 || !M5 || w < 1 || h < 1) return TW_E_BAD_PARAMETER;
+    TW_HIP(e, hipSetDevice(e->device));
+    const int ld = round_up(w, 32);
+    const long long ps = (long long)ld * h;
+    Tmp t;
+    float *d_R0 = t.alloc<float>(ps * 5), *d_R1 = t.alloc<float>(ps * 5), *d_M = t.alloc<float>(ps * 5),
+          *d_f = t.alloc<float>(ps * 2);
+    if (!d_R0 || !d_R1 || !d_M || !d_f) return TW_E_NOMEM;
+    tw_status r;
+    if ((r = up_planes(e, d_R0, ld, ps, R0_5, w, h, 5)) || (r = up_planes(e, d_R1, ld, ps, R1_5, w, h, 5)) ||
+        (r = up_planes(e, d_f, ld, ps, flow2, w, h, 2)))
+        return r;
+    UpdArgs a;
+    memset(&a, 0, sizeof(a));
+    a.R0 = d_R0;
+    a.R1 = d_R1;
+    a.flow = d_f;
+    a.M = d_M;
+    a.w = w;
+    a.h = h;
+    a.ld = ld;
+    a.ps = ps;
+    a.fps = ps;
+    hipStream_t st = e->slots[0].stream;
+    hipLaunchKernelGGL(tw_update_matrices<false>, dim3((w + 63) / 64, (h + 3) / 4), dim3(256), 0, st, a);
+    TW_HIP(e, hipGetLastError());
+    TW_HIP(e, hipStreamSynchronize(st));
+    return down_planes(e, M5, d_M, ld, ps, w, h, 5);
+}
+
+tw_status tw_stage_flow_upsample_update(tw_engine* e, const float* R0_5, const float* R1_5, const float* prevflow2,
+                                        int pw, int ph, int w, int h, float* flow2, float* M5)
+{
+    if (!e || !R0_5 || !R1_5 || !prevflow2 || !flow2 || !M5 || w < 1 || h < 1 || pw < 1 || ph < 1)
+        return TW_E_BAD_PARAMETER;
+    TW_HIP(e, hipSetDevice(e->device));
+    const int ld = round_up(w, 32), pld = round_up(pw, 32);
+    const long long ps = (long long)ld * h, pps = (long long)pld * ph;
+    ResizeTab u;
+    make_resize_tab(pw, ph, w, h, u);
+    if (u.mode == 2) return TW_E_UNSUPPORTED;
+    Tmp t;
+    float *d_R0 = t.alloc<float>(ps * 5), *d_R1 = t.alloc<float>(ps * 5), *d_M = t.alloc<float>(ps * 5),
+          *d_f = t.alloc<float>(ps * 2), *d_p = t.alloc<float>(pps * 2);
+    int *d_xo = t.alloc<int>(w), *d_yo = t.alloc<int>(h);
+    float *d_al = t.alloc<float>(2 * (size_t)w), *d_be = t.alloc<float>(2 * (size_t)h);
+    if (!d_R0 || !d_R1 || !d_M || !d_f || !d_p || !d_xo || !d_yo || !d_al || !d_be) return TW_E_NOMEM;
+    tw_status r;
+    if ((r = up_planes(e, d_R0, ld, ps, R0_5, w, h, 5)) || (r = up_planes(e, d_R1, ld, ps, R1_5, w, h, 5)) ||
+        (r = up_planes(e, d_p, pld, pps, prevflow2, pw, ph, 2)))
+        return r;
+    TW_HIP(e, hipMemcpy(d_xo, u.xofs.data(), (size_t)w * 4, hipMemcpyHostToDevice));
+    TW_HIP(e, hipMemcpy(d_yo, u.yofs.data(), (size_t)h * 4, hipMemcpyHostToDevice));
+    TW_HIP(e, hipMemcpy(d_al, u.alpha.data(), (size_t)w * 8, hipMemcpyHostToDevice));
+    TW_HIP(e, hipMemcpy(d_be, u.beta.data(), (size_t)h * 8, hipMemcpyHostToDevice));
+    UpdArgs a;
+    memset(&a, 0, sizeof(a));
+    a.R0 = d_R0;
+    a.R1 = d_R1;
+    a.flow = d_f;
+    a.M = d_M;
+    a.w = w;
+    a.h = h;
+    a.ld = ld;
+    a.ps = ps;
+    a.fps = ps;
+    a.prev = d_p;
+    a.pw = pw;
+    a.ph = ph;
+    a.pld = pld;
+    a.pfps = pps;
+    a.xofs = d_xo;
+    a.alpha = d_al;
+    a.yofs = d_yo;
+    a.beta = d_be;
+    a.xmax = u.xmax;
+    a.scale = (float)(1. / e->p.pyrScale);
+    hipStream_t st = e->slots[0].stream;
+    hipLaunchKernelGGL(tw_update_matrices<true>, dim3((w + 63) / 64, (h + 3) / 4), dim3(256), 0, st, a);
+    TW_HIP(e, hipGetLastError());
+    TW_HIP(e, hipStreamSynchronize(st));
+    if ((r = down_planes(e, flow2, d_f, ld, ps, w, h, 2))) return r;
+    return down_planes(e, M5, d_M, ld, ps, w, h, 5);
+}
+
+tw_status tw_stage_blur_solve(tw_engine* e, const float* R0_5, const float* R1_5, const float* M5, int w, int h,
+                              int update_matrices, float* flow2, float* Mout5)
+{
+    if (!e || !R0_5 || !R1_5 || !M5 || !flow2 || w < 1 || h < 1) return TW_E_BAD_PARAMETER;
+    if (update_matrices && !Mout5) return TW_E_BAD_PARAMETER;
+    TW_HIP(e, hipSetDevice(e->device));
+    const int ld = round_up(w, 32);
+    const long long ps = (long long)ld * h;
+    Tmp t;
+    float *d_R0 = t.alloc<float>(ps * 5), *d_R1 = t.alloc<float>(ps * 5), *d_M = t.alloc<float>(ps * 5),
+          *d_Mo = t.alloc<float>(ps * 5), *d_f = t.alloc<float>(ps * 2);
+    if (!d_R0 || !d_R1 || !d_M || !d_Mo || !d_f) return TW_E_NOMEM;
+    tw_status r;
+    if ((r = up_planes(e, d_R0, ld, ps, R0_5, w, h, 5)) || (r = up_planes(e, d_R1, ld, ps, R1_5, w, h, 5)) ||
+        (r = up_planes(e, d_M, ld, ps, M5, w, h, 5)))
+        return r;
+    hipStream_t st = e->slots[0].stream;
+    launch_blur(e, st, w, h, ld, ps, d_M, d_Mo, d_f, d_R0, d_R1, update_matrices ? 1 : 0, -1);
+    TW_HIP(e, hipGetLastError());
+    TW_HIP(e, hipStreamSynchronize(st));
+    if ((r = down_planes(e, flow2, d_f, ld, ps, w, h, 2))) return r;
+    if (update_matrices) return down_planes(e, Mout5, d_Mo, ld, ps, w, h, 5);
+    return TW_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,629 @@
+// twflow_kernels.hip.h — hand-written gfx950 (CDNA4, wave64) kernels of the Farneback image-diff path.
+//
+// Every kernel mirrors, operation by operation, the float/double arithmetic of OpenCV 2.4.9's CPU
+// cv::calcOpticalFlowFarneback (the call at /root/reference/src/opticalflow.cpp:83-85) so that results are
+// bit-identical to the CPU path; this translation unit is compiled with -ffp-contract=off and uses an
+// explicit fma only where the product is exact in the wider type (so fused == unfused).
+//
+// Layout in HBM: every float image is a dense plane with row pitch `ld` (multiple of 32 floats); R (polynomial
+// coefficients) and M (G11,G12,G22,h1,h2) are 5 planes at plane stride `ps`; flow is 2 planes.
+// This is a stencil / gather path: HBM- and LDS-bound, no MFMA.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace twk {
+
+typedef float __attribute__((ext_vector_type(4))) f32x4;
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// borderInterpolate(p, len, BORDER_REFLECT_101)
+__device__ __forceinline__ int reflect101(int p, int len)
+{
+    if ((unsigned)p < (unsigned)len) return p;
+    if (len == 1) return 0;
+    do {
+        if (p < 0) p = -p;
+        else p = 2 * len - 2 - p;
+    } while ((unsigned)p >= (unsigned)len);
+    return p;
+}
+
+// =====================================================================================================
+// K1  tw_pyr_level : u8 full-res image -> f32 pyramid level
+//   convertTo(CV_32F) + GaussianBlur(smooth_sz, sigma, REFLECT_101) on the FULL-RES image + resize(INTER_LINEAR)
+//   (OpenCV 2.4.9 optflowgf.cpp level loop).  Fused: the blur is evaluated only at the <=2x2 full-res samples
+//   each output pixel reads.  Row filter of the needed source rows/columns goes to LDS, column filter +
+//   bilinear (or 2x2 area-fast) combine reads it back.
+// =====================================================================================================
+constexpr int PYR_TW = 32;  // output tile
+constexpr int PYR_TH = 8;
+constexpr int PYR_MAXK = 128;
+
+struct PyrArgs {
+    const uint8_t* src[2];  // two images per launch (blockIdx.z)
+    float* dst[2];
+    long long stride;  // bytes
+    int w0, h0;
+    int w, h, ld;
+    const int* xofs;     // [w]   source column of the left tap
+    const float* alpha;  // [2w]  (1-fx, fx)
+    const int* yofs;     // [h]   UNCLIPPED source row of the top tap (rows are clipped, weights are not)
+    const float* beta;   // [2h]
+    const float* kern;   // [ksize] getGaussianKernel(ksize, sigma, CV_32F)
+    int ksize;
+    int mode;  // 0: same size (identity resize), 1: INTER_LINEAR, 2: 2x2 INTER_AREA fast path
+    int xmax;  // dx >= xmax: single-tap columns (HResizeLinear tail loop)
+    int nrows_max;
+};
+
+__global__ __launch_bounds__(256) void tw_pyr_level(PyrArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float pyr_sm[];
+    float* skern = pyr_sm;               // [PYR_MAXK]
+    float* rowbuf = pyr_sm + PYR_MAXK;   // [nrows][P]
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * PYR_TW, y0 = blockIdx.y * PYR_TH;
+    const uint8_t* __restrict__ src = a.src[blockIdx.z];
+    float* __restrict__ dst = a.dst[blockIdx.z];
+    const int ksize = a.ksize, r = ksize >> 1;
+    const int P = (a.mode == 0) ? PYR_TW : 2 * PYR_TW;
+
+    if (tid < ksize) skern[tid] = a.kern[tid];
+    const int yA = y0, yB = min(y0 + PYR_TH - 1, a.h - 1);
+    const int ylo = clampi(a.yofs[yA], 0, a.h0 - 1) - r;
+    const int yhi = clampi(a.yofs[yB] + 1, 0, a.h0 - 1) + r;
+    const int nrows = yhi - ylo + 1;
+    __syncthreads();
+
+    // ---- row filter (float) of source rows [ylo,yhi] at the needed columns ----
+    const float* kc = skern + r;
+    for (int it = tid; it < nrows * P; it += 256) {
+        const int rr = it / P, p = it - rr * P;
+        int ox = x0 + ((a.mode == 0) ? p : (p >> 1));
+        ox = min(ox, a.w - 1);
+        const int X = (a.mode == 0) ? ox : (a.xofs[ox] + (p & 1));
+        const int Y = reflect101(ylo + rr, a.h0);
+        const uint8_t* __restrict__ S = src + (long long)Y * a.stride;
+        float s;
+        if (ksize == 3) {
+            const float c = (float)S[reflect101(X, a.w0)];
+            const float l = (float)S[reflect101(X - 1, a.w0)], rt = (float)S[reflect101(X + 1, a.w0)];
+            s = c * kc[0] + (l + rt) * kc[1];
+        } else if (ksize == 5) {
+            const float c = (float)S[reflect101(X, a.w0)];
+            const float l1 = (float)S[reflect101(X - 1, a.w0)], r1 = (float)S[reflect101(X + 1, a.w0)];
+            const float l2 = (float)S[reflect101(X - 2, a.w0)], r2 = (float)S[reflect101(X + 2, a.w0)];
+            s = c * kc[0] + (l1 + r1) * kc[1] + (l2 + r2) * kc[2];
+        } else if (ksize == 1) {
+            s = (float)S[reflect101(X, a.w0)] * kc[0];
+        } else {
+            s = skern[0] * (float)S[reflect101(X - r, a.w0)];
+            for (int j = 1; j < ksize; j++) s += skern[j] * (float)S[reflect101(X - r + j, a.w0)];
+        }
+        rowbuf[rr * P + p] = s;
+    }
+    __syncthreads();
+
+    // ---- column filter at the sampled rows + resize combine ----
+    const int tx = tid & (PYR_TW - 1), ty = tid / PYR_TW;
+    const int ox = x0 + tx, oy = y0 + ty;
+    if (ox >= a.w || oy >= a.h) return;
+    const int sy = a.yofs[oy];
+    const int s0 = clampi(sy, 0, a.h0 - 1) - ylo, s1 = clampi(sy + 1, 0, a.h0 - 1) - ylo;
+
+    auto colf = [&](int srow, int p) -> float {
+        const float* R = rowbuf + srow * P + p;
+        if (ksize == 3) return (R[-P] + R[P]) * kc[1] + R[0] * kc[0];
+        if (ksize == 1) return kc[0] * R[0];
+        float s = kc[0] * R[0];
+        for (int j = 1; j <= r; j++) s += kc[j] * (R[j * P] + R[-j * P]);
+        return s;
+    };
+
+    float out;
+    if (a.mode == 0) {
+        out = colf(s0, tx);
+    } else if (a.mode == 2) {
+        float sum = 0.f;
+        sum += colf(s0, 2 * tx) + colf(s0, 2 * tx + 1) + colf(s1, 2 * tx) + colf(s1, 2 * tx + 1);
+        out = sum * 0.25f;
+    } else {
+        float t0, t1;
+        if (ox < a.xmax) {
+            const float a0 = a.alpha[2 * ox], a1 = a.alpha[2 * ox + 1];
+            t0 = colf(s0, 2 * tx) * a0 + colf(s0, 2 * tx + 1) * a1;
+            t1 = colf(s1, 2 * tx) * a0 + colf(s1, 2 * tx + 1) * a1;
+        } else {
+            t0 = colf(s0, 2 * tx) * 1.f;
+            t1 = colf(s1, 2 * tx) * 1.f;
+        }
+        out = t0 * a.beta[2 * oy] + t1 * a.beta[2 * oy + 1];
+    }
+    dst[(long long)oy * a.ld + ox] = out;
+}
+
+// =====================================================================================================
+// K5  tw_polyexp<N> : FarnebackPolyExp (optflowgf.cpp) — the roofline-graded kernel, 24 B/px algorithmic.
+//   Tile = 240 columns x 8 rows per 256-thread workgroup (240 + 2x8 halo columns = 256 = one column per
+//   thread for the vertical pass).  Vertical pass (float, 2N+1 taps) runs from a register window of the
+//   TH+2N source rows of the thread's column; its three moment rows go to LDS; the horizontal pass (double
+//   accumulators, as the CPU code) reads 20-float windows per plane with ds_read_b128 and produces 4 pixels
+//   per work item; 5 coefficient planes are stored as 16-byte vectors.
+// =====================================================================================================
+constexpr int PE_TW = 240, PE_TH = 8, PE_COLS = 256, PE_HALO = 8;
+
+struct PolyCoef {
+    float g[8], xg[8], xxg[8];  // index k = 0..N
+    double ig11, ig03, ig33, ig55;
+};
+
+struct PolyArgs {
+    const float* src[2];
+    float* dst[2];
+    int w, h, ld;
+    long long ps;  // plane stride (elements) of dst
+    PolyCoef c;
+};
+
+template <int N>
+__global__ __launch_bounds__(256) void tw_polyexp(PolyArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float sm[3][PE_TH][PE_COLS];
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * PE_TW, y0 = blockIdx.y * PE_TH;
+    const float* __restrict__ src = a.src[blockIdx.z];
+    float* __restrict__ dst = a.dst[blockIdx.z];
+    const PolyCoef& c = a.c;
+
+    // ---- vertical pass: one column per thread, rows y0-N .. y0+TH-1+N in registers ----
+    {
+        const int x = clampi(x0 - PE_HALO + tid, 0, a.w - 1);
+        float win[PE_TH + 2 * N];
+#pragma unroll
+        for (int i = 0; i < PE_TH + 2 * N; i++) {
+            const int y = clampi(y0 - N + i, 0, a.h - 1);
+            win[i] = src[(long long)y * a.ld + x];
+        }
+#pragma unroll
+        for (int r = 0; r < PE_TH; r++) {
+            float t0 = win[r + N] * c.g[0], t1 = 0.f, t2 = 0.f;
+#pragma unroll
+            for (int k = 1; k <= N; k++) {
+                const float s0 = win[r + N - k], s1 = win[r + N + k];  // rows y-k, y+k
+                const float p = s0 + s1;
+                t0 = t0 + c.g[k] * p;
+                t1 = t1 + c.xg[k] * (s1 - s0);
+                t2 = t2 + c.xxg[k] * p;
+            }
+            sm[0][r][tid] = t0;
+            sm[1][r][tid] = t1;
+            sm[2][r][tid] = t2;
+        }
+    }
+    __syncthreads();
+
+    // ---- horizontal pass: items = 8 rows x 60 groups of 4 pixels ----
+    constexpr int GROUPS = PE_TW / 4;
+    for (int it = tid; it < PE_TH * GROUPS; it += 256) {
+        const int r = it / GROUPS, q = it - r * GROUPS;
+        const int y = y0 + r, x = x0 + 4 * q;
+        if (y >= a.h || x >= a.w) continue;
+        float w0[20], w1[20], w2[20];
+#pragma unroll
+        for (int v = 0; v < 5; v++) {
+            const f32x4 A = *(const f32x4*)&sm[0][r][4 * q + 4 * v];
+            const f32x4 B = *(const f32x4*)&sm[1][r][4 * q + 4 * v];
+            const f32x4 C = *(const f32x4*)&sm[2][r][4 * q + 4 * v];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                w0[4 * v + e] = A[e];
+                w1[4 * v + e] = B[e];
+                w2[4 * v + e] = C[e];
+            }
+        }
+        float o0[4], o1[4], o2[4], o3[4], o4[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int li = PE_HALO + j;
+            const float g0 = c.g[0];
+            double b1 = (double)(w0[li] * g0), b2 = 0, b3 = (double)(w1[li] * g0), b4 = 0,
+                   b5 = (double)(w2[li] * g0), b6 = 0;
+#pragma unroll
+            for (int k = 1; k <= N; k++) {
+                const float gk = c.g[k], xgk = c.xg[k], xxgk = c.xxg[k];
+                const double tg = (double)(w0[li + k] + w0[li - k]);
+                // tg, gk, xxgk are floats widened to double: the products are exact, fma == mul+add
+                b1 = __builtin_fma(tg, (double)gk, b1);
+                b4 = __builtin_fma(tg, (double)xxgk, b4);
+                b2 += (double)((w0[li + k] - w0[li - k]) * xgk);
+                b3 += (double)((w1[li + k] + w1[li - k]) * gk);
+                b6 += (double)((w1[li + k] - w1[li - k]) * xgk);
+                b5 += (double)((w2[li + k] + w2[li - k]) * gk);
+            }
+            o1[j] = (float)(b2 * c.ig11);
+            o0[j] = (float)(b3 * c.ig11);
+            o3[j] = (float)(b1 * c.ig03 + b4 * c.ig33);
+            o2[j] = (float)(b1 * c.ig03 + b5 * c.ig33);
+            o4[j] = (float)(b6 * c.ig55);
+        }
+        float* d = dst + (long long)y * a.ld + x;
+        if (x + 3 < a.w) {
+            *(f32x4*)(d) = f32x4{o0[0], o0[1], o0[2], o0[3]};
+            *(f32x4*)(d + a.ps) = f32x4{o1[0], o1[1], o1[2], o1[3]};
+            *(f32x4*)(d + 2 * a.ps) = f32x4{o2[0], o2[1], o2[2], o2[3]};
+            *(f32x4*)(d + 3 * a.ps) = f32x4{o3[0], o3[1], o3[2], o3[3]};
+            *(f32x4*)(d + 4 * a.ps) = f32x4{o4[0], o4[1], o4[2], o4[3]};
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (x + j < a.w) {
+                    d[j] = o0[j];
+                    d[j + a.ps] = o1[j];
+                    d[j + 2 * a.ps] = o2[j];
+                    d[j + 3 * a.ps] = o3[j];
+                    d[j + 4 * a.ps] = o4[j];
+                }
+        }
+    }
+}
+
+// =====================================================================================================
+// FarnebackUpdateMatrices for one pixel (optflowgf.cpp): warp R1 by the flow (bilinear gather of 5
+// coefficients), combine with R0, border attenuation, form G11,G12,G22,h1,h2.  All float.
+// =====================================================================================================
+__device__ __forceinline__ void update_matrices_px(const float* __restrict__ R0, const float* __restrict__ R1,
+                                                   long long ps, int ld, int w, int h, int x, int y, float dx,
+                                                   float dy, float M[5])
+{
+    const long long o = (long long)y * ld + x;
+    float fx = (float)x + dx, fy = (float)y + dy;
+    const float flx = floorf(fx), fly = floorf(fy);
+    float r2, r3, r4, r5, r6;
+    // (unsigned)x1 < (unsigned)(w-1) && (unsigned)y1 < (unsigned)(h-1), with cvFloor's INT_MIN for
+    // out-of-range / NaN inputs: evaluated on the floats (exact: |.| < 2^24 inside the branch)
+    if (flx >= 0.f && flx < (float)(w - 1) && fly >= 0.f && fly < (float)(h - 1)) {
+        const int x1 = (int)flx, y1 = (int)fly;
+        fx -= (float)x1;
+        fy -= (float)y1;
+        const float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
+        const float* p = R1 + (long long)y1 * ld + x1;
+        r2 = a00 * p[0] + a01 * p[1] + a10 * p[ld] + a11 * p[ld + 1];
+        p += ps;
+        r3 = a00 * p[0] + a01 * p[1] + a10 * p[ld] + a11 * p[ld + 1];
+        p += ps;
+        r4 = a00 * p[0] + a01 * p[1] + a10 * p[ld] + a11 * p[ld + 1];
+        p += ps;
+        r5 = a00 * p[0] + a01 * p[1] + a10 * p[ld] + a11 * p[ld + 1];
+        p += ps;
+        r6 = a00 * p[0] + a01 * p[1] + a10 * p[ld] + a11 * p[ld + 1];
+        r4 = (R0[o + 2 * ps] + r4) * 0.5f;
+        r5 = (R0[o + 3 * ps] + r5) * 0.5f;
+        r6 = (R0[o + 4 * ps] + r6) * 0.25f;
+    } else {
+        r2 = r3 = 0.f;
+        r4 = R0[o + 2 * ps];
+        r5 = R0[o + 3 * ps];
+        r6 = R0[o + 4 * ps] * 0.5f;
+    }
+    r2 = (R0[o] - r2) * 0.5f;
+    r3 = (R0[o + ps] - r3) * 0.5f;
+    r2 += r4 * dy + r6 * dx;
+    r3 += r6 * dy + r5 * dx;
+    constexpr int BORDER = 5;
+    if ((unsigned)(x - BORDER) >= (unsigned)(w - BORDER * 2) || (unsigned)(y - BORDER) >= (unsigned)(h - BORDER * 2)) {
+        const float border[BORDER] = {0.14f, 0.14f, 0.4472f, 0.4472f, 0.4472f};
+        float bx0 = 1.f, bx1 = 1.f, by0 = 1.f, by1 = 1.f;
+#pragma unroll
+        for (int i = 0; i < BORDER; i++) {
+            if (x == i) bx0 = border[i];
+            if (w - x - 1 == i) bx1 = border[i];
+            if (y == i) by0 = border[i];
+            if (h - y - 1 == i) by1 = border[i];
+        }
+        const float scale = bx0 * bx1 * by0 * by1;
+        r2 *= scale;
+        r3 *= scale;
+        r4 *= scale;
+        r5 *= scale;
+        r6 *= scale;
+    }
+    M[0] = r4 * r4 + r6 * r6;
+    M[1] = (r4 + r5) * r6;
+    M[2] = r5 * r5 + r6 * r6;
+    M[3] = r4 * r2 + r6 * r3;
+    M[4] = r6 * r2 + r5 * r3;
+}
+
+// =====================================================================================================
+// K6  tw_update_matrices<UPSAMPLE> : first FarnebackUpdateMatrices of a level.  UPSAMPLE fuses
+//   resize(prevFlow, INTER_LINEAR) + flow *= 1/pyr_scale (and writes the level's initial flow);
+//   otherwise the flow planes are read (zero-initialised at the coarsest level).
+// =====================================================================================================
+struct UpdArgs {
+    const float* R0;
+    const float* R1;
+    float* flow;  // 2 planes, plane stride fps
+    float* M;
+    int w, h, ld;
+    long long ps, fps;
+    // upsample source
+    const float* prev;  // 2 planes
+    int pw, ph, pld;
+    long long pfps;
+    const int* xofs;
+    const float* alpha;
+    const int* yofs;
+    const float* beta;
+    int xmax;
+    float scale;  // (float)(1/pyr_scale)
+    int zero_flow;  // coarsest level: flow = 0 (written)
+};
+
+template <bool UPSAMPLE>
+__global__ __launch_bounds__(256) void tw_update_matrices(UpdArgs a)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= a.w || y >= a.h) return;
+    const long long o = (long long)y * a.ld + x;
+    float dx, dy;
+    if (UPSAMPLE) {
+        const int sx = a.xofs[x];
+        const int sy = a.yofs[y];
+        const int r0 = clampi(sy, 0, a.ph - 1), r1 = clampi(sy + 1, 0, a.ph - 1);
+        const float b0 = a.beta[2 * y], b1 = a.beta[2 * y + 1];
+        const float* P0 = a.prev + (long long)r0 * a.pld + sx;
+        const float* P1 = a.prev + (long long)r1 * a.pld + sx;
+        float t0x, t1x, t0y, t1y;
+        if (x < a.xmax) {
+            const float a0 = a.alpha[2 * x], a1 = a.alpha[2 * x + 1];
+            t0x = P0[0] * a0 + P0[1] * a1;
+            t1x = P1[0] * a0 + P1[1] * a1;
+            t0y = P0[a.pfps] * a0 + P0[a.pfps + 1] * a1;
+            t1y = P1[a.pfps] * a0 + P1[a.pfps + 1] * a1;
+        } else {
+            t0x = P0[0] * 1.f;
+            t1x = P1[0] * 1.f;
+            t0y = P0[a.pfps] * 1.f;
+            t1y = P1[a.pfps] * 1.f;
+        }
+        dx = (t0x * b0 + t1x * b1) * a.scale + 0.f;
+        dy = (t0y * b0 + t1y * b1) * a.scale + 0.f;
+        a.flow[o] = dx;
+        a.flow[o + a.fps] = dy;
+    } else if (a.zero_flow) {
+        dx = dy = 0.f;
+        a.flow[o] = 0.f;
+        a.flow[o + a.fps] = 0.f;
+    } else {
+        dx = a.flow[o];
+        dy = a.flow[o + a.fps];
+    }
+    float M[5];
+    update_matrices_px(a.R0, a.R1, a.ps, a.ld, a.w, a.h, x, y, dx, dy, M);
+#pragma unroll
+    for (int c = 0; c < 5; c++) a.M[o + c * a.ps] = M[c];
+}
+
+// =====================================================================================================
+// K7+K8 (+K6)  tw_blur_solve<MH,COLS,HALO> : FarnebackUpdateFlow_GaussianBlur (optflowgf.cpp).
+//   (2*MH+1)-tap window average of the 5 M planes (float, centre-out pair order, replicate borders),
+//   2x2 solve in double with the +1e-3 regulariser, and — fused — the FarnebackUpdateMatrices refresh of
+//   the same pixel into the other M buffer (the CPU code's stripe-wise refresh is equivalent to
+//   "whole new flow from old M, then whole new M": optflowgf.cpp y1 = y - block_size bookkeeping).
+//   Tile = (COLS-2*HALO) columns x 8 rows; vertical pass from a register window of 8+2*MH rows per column,
+//   blurred rows of all 5 planes staged in LDS, horizontal pass 4 pixels per item from ds_read_b128 windows.
+// =====================================================================================================
+constexpr int BS_TH = 8;
+
+struct WinCoef {
+    float k[33];  // kernel[0..m]
+};
+
+struct BlurArgs {
+    const float* Min;
+    float* Mout;
+    float* flow;
+    const float* R0;
+    const float* R1;
+    int w, h, ld;
+    long long ps, fps;
+    int update;  // refresh M (i < iterations-1)
+    int m;       // runtime m for the generic kernel
+    WinCoef c;
+};
+
+template <int MH, int COLS, int HALO>
+__global__ __launch_bounds__(COLS) void tw_blur_solve(BlurArgs a)
+{
+    constexpr int TW = COLS - 2 * HALO;
+    __shared__ __attribute__((aligned(16))) float sm[5][BS_TH][COLS];
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * BS_TH;
+    const WinCoef& c = a.c;
+
+    // ---- vertical blur: one column per thread ----
+    {
+        const int x = clampi(x0 - HALO + tid, 0, a.w - 1);
+#pragma unroll 1
+        for (int ch = 0; ch < 5; ch++) {
+            const float* __restrict__ Mp = a.Min + ch * a.ps + x;
+            float win[BS_TH + 2 * MH];
+#pragma unroll
+            for (int i = 0; i < BS_TH + 2 * MH; i++) {
+                const int y = clampi(y0 - MH + i, 0, a.h - 1);
+                win[i] = Mp[(long long)y * a.ld];
+            }
+#pragma unroll
+            for (int r = 0; r < BS_TH; r++) {
+                float s0 = win[r + MH] * c.k[0];
+#pragma unroll
+                for (int i = 1; i <= MH; i++) s0 += (win[r + MH + i] + win[r + MH - i]) * c.k[i];
+                sm[ch][r][tid] = s0;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- horizontal blur + solve (+ matrix refresh): items = 8 rows x TW/4 groups ----
+    constexpr int GROUPS = TW / 4;
+    constexpr int WL = 4 + 2 * HALO;
+    for (int it = tid; it < BS_TH * GROUPS; it += COLS) {
+        const int r = it / GROUPS, q = it - r * GROUPS;
+        const int y = y0 + r, x = x0 + 4 * q;
+        if (y >= a.h || x >= a.w) continue;
+        float hs[5][4];
+#pragma unroll
+        for (int ch = 0; ch < 5; ch++) {
+            float v[WL];
+#pragma unroll
+            for (int u = 0; u < WL / 4; u++) {
+                const f32x4 A = *(const f32x4*)&sm[ch][r][4 * q + 4 * u];
+                v[4 * u] = A[0];
+                v[4 * u + 1] = A[1];
+                v[4 * u + 2] = A[2];
+                v[4 * u + 3] = A[3];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int li = HALO + j;
+                float sum = v[li] * c.k[0];
+#pragma unroll
+                for (int i = 1; i <= MH; i++) sum += c.k[i] * (v[li - i] + v[li + i]);
+                hs[ch][j] = sum;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (x + j >= a.w) break;
+            const double g11 = hs[0][j], g12 = hs[1][j], g22 = hs[2][j], h1 = hs[3][j], h2 = hs[4][j];
+            const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
+            const float fxv = (float)((g11 * h2 - g12 * h1) * idet);
+            const float fyv = (float)((g22 * h1 - g12 * h2) * idet);
+            const long long o = (long long)y * a.ld + x + j;
+            a.flow[o] = fxv;
+            a.flow[o + a.fps] = fyv;
+            if (a.update) {
+                float M[5];
+                update_matrices_px(a.R0, a.R1, a.ps, a.ld, a.w, a.h, x + j, y, fxv, fyv, M);
+#pragma unroll
+                for (int cc = 0; cc < 5; cc++) a.Mout[o + cc * a.ps] = M[cc];
+            }
+        }
+    }
+}
+
+// Generic window size (any m <= 32): same arithmetic, runtime loops, one pixel per thread, no register
+// window.  Slow path for non-default winSize.
+__global__ __launch_bounds__(256) void tw_blur_solve_generic(BlurArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float gsm[];  // [5][8][64+2m]
+    const int m = a.m;
+    const int CW = 64 + 2 * m;
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * 64, y0 = blockIdx.y * BS_TH;
+    for (int it = tid; it < 5 * BS_TH * CW; it += 256) {
+        const int ch = it / (BS_TH * CW);
+        const int rem = it - ch * BS_TH * CW;
+        const int r = rem / CW, cix = rem - r * CW;
+        const int x = clampi(x0 - m + cix, 0, a.w - 1);
+        const int y = y0 + r;
+        const float* __restrict__ Mp = a.Min + ch * a.ps + x;
+        float s0 = Mp[(long long)clampi(y, 0, a.h - 1) * a.ld] * a.c.k[0];
+        for (int i = 1; i <= m; i++)
+            s0 += (Mp[(long long)clampi(y + i, 0, a.h - 1) * a.ld] + Mp[(long long)clampi(y - i, 0, a.h - 1) * a.ld]) *
+                  a.c.k[i];
+        gsm[it] = s0;
+    }
+    __syncthreads();
+    for (int it = tid; it < BS_TH * 64; it += 256) {
+        const int r = it >> 6, cx = it & 63;
+        const int x = x0 + cx, y = y0 + r;
+        if (x >= a.w || y >= a.h) continue;
+        float hs[5];
+        for (int ch = 0; ch < 5; ch++) {
+            const float* v = gsm + (ch * BS_TH + r) * CW + cx + m;
+            float sum = v[0] * a.c.k[0];
+            for (int i = 1; i <= m; i++) sum += a.c.k[i] * (v[-i] + v[i]);
+            hs[ch] = sum;
+        }
+        const double g11 = hs[0], g12 = hs[1], g22 = hs[2], h1 = hs[3], h2 = hs[4];
+        const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
+        const float fxv = (float)((g11 * h2 - g12 * h1) * idet);
+        const float fyv = (float)((g22 * h1 - g12 * h2) * idet);
+        const long long o = (long long)y * a.ld + x;
+        a.flow[o] = fxv;
+        a.flow[o + a.fps] = fyv;
+        if (a.update) {
+            float M[5];
+            update_matrices_px(a.R0, a.R1, a.ps, a.ld, a.w, a.h, x, y, fxv, fyv, M);
+            for (int cc = 0; cc < 5; cc++) a.Mout[o + cc * a.ps] = M[cc];
+        }
+    }
+}
+
+// =====================================================================================================
+// K12  tw_span_scan : the span-grid threshold scan of /root/reference/src/consumer.cpp:60-76.
+//   len = dx*dx + dy*dy in float, compared in double against threshold*threshold (strict >);
+//   flagged grid vectors are compacted in the reference's row-major order by one 1024-thread workgroup
+//   (count -> LDS scan -> ordered write), so only the hits cross PCIe.
+// =====================================================================================================
+struct ScanRec {
+    int x, y;
+    float dx, dy;
+};
+struct ScanArgs {
+    const float* flow;
+    long long fps;
+    int w, h, ld;
+    int span, gw, gh;
+    double thr2;
+    int* count;    // [1]
+    ScanRec* rec;  // [gw*gh]
+};
+
+__global__ __launch_bounds__(1024) void tw_span_scan(ScanArgs a)
+{
+    __shared__ int part[1024];
+    const int tid = threadIdx.x;
+    const int G = a.gw * a.gh;
+    const int per = (G + 1023) / 1024;
+    const int b = tid * per, e = min(b + per, G);
+    int cnt = 0;
+    for (int i = b; i < e; i++) {
+        const int gy = i / a.gw, gx = i - gy * a.gw;
+        const long long o = (long long)(gy * a.span) * a.ld + gx * a.span;
+        const float dx = a.flow[o], dy = a.flow[o + a.fps];
+        const float len = (dx * dx) + (dy * dy);
+        cnt += ((double)len > a.thr2) ? 1 : 0;
+    }
+    part[tid] = cnt;
+    __syncthreads();
+    // Hillis-Steele inclusive scan over 1024 partial counts
+    for (int off = 1; off < 1024; off <<= 1) {
+        int v = (tid >= off) ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int pos = part[tid] - cnt;
+    if (tid == 1023) a.count[0] = part[1023];
+    for (int i = b; i < e; i++) {
+        const int gy = i / a.gw, gx = i - gy * a.gw;
+        const long long o = (long long)(gy * a.span) * a.ld + gx * a.span;
+        const float dx = a.flow[o], dy = a.flow[o + a.fps];
+        const float len = (dx * dx) + (dy * dy);
+        if ((double)len > a.thr2) {
+            ScanRec rr;
+            rr.x = gx * a.span;
+            rr.y = gy * a.span;
+            rr.dx = dx;
+            rr.dy = dy;
+            a.rec[pos++] = rr;
+        }
+    }
+}
+
+}  // namespace twk

@@ -1,0 +1,306 @@
+"""ctypes binding of libtwflow.so (include/twflow.h) — test / bench plumbing.
+
+The product is the C-ABI HIP library; this module only marshals numpy arrays into it.  There is no
+fallback of any kind: if the library is missing or no HIP device is usable, calls raise.
+
+Names follow the reference: `Engine.calculate_internal` is OpticalFlow::calculateInternal
+(/root/reference/src/opticalflow.h:49), `Engine.diff` is the flow + span-grid scan of
+Consumer::run (/root/reference/src/consumer.cpp:54-84) and returns the fields of `Response`
+(/root/reference/src/message_queue.h:27-42).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtwflow.so")
+
+TW_OK, TW_E_BAD_PARAMETER, TW_E_BAD_IMAGE_FORMAT, TW_E_DONT_MATCH_SIZE = 0, 1, 2, 3
+TW_E_DEVICE, TW_E_NOMEM, TW_E_UNSUPPORTED, TW_E_BUSY = 4, 5, 6, 7
+K_PYR, K_POLYEXP, K_UPDATE_MATRICES, K_BLUR_SOLVE, K_SCAN = 0, 1, 2, 3, 4
+KERNEL_NAMES = {K_PYR: "tw_pyr_level", K_POLYEXP: "tw_polyexp", K_UPDATE_MATRICES: "tw_update_matrices",
+                K_BLUR_SOLVE: "tw_blur_solve", K_SCAN: "tw_span_scan"}
+
+
+class Params(C.Structure):
+    # tw_params == struct OpticalFlowParameter, /root/reference/src/opticalflow.h:28-36
+    _fields_ = [("pyrScale", C.c_double), ("pyrLevels", C.c_int), ("winSize", C.c_int),
+                ("pyrIterations", C.c_int), ("polyN", C.c_int), ("polySigma", C.c_double),
+                ("flags", C.c_int)]
+
+
+class Vector(C.Structure):
+    # tw_vector == struct Vector, /root/reference/src/message_queue.h:20-25
+    _fields_ = [("x", C.c_int), ("y", C.c_int), ("dx", C.c_double), ("dy", C.c_double)]
+
+
+class TwError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("twflow status %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+# every symbol include/twflow.h declares
+SYMBOLS = [
+    "tw_default_params", "tw_device_count", "tw_engine_create", "tw_engine_destroy", "tw_strerror",
+    "tw_last_error", "tw_flow_u8", "tw_diff_u8", "tw_submit_u8", "tw_submit_dev", "tw_wait",
+    "tw_grid_capacity", "tw_dev_alloc", "tw_dev_free", "tw_dev_upload", "tw_prof_select", "tw_prof_read",
+    "tw_algorithmic_bytes", "tw_algorithmic_bytes_pair", "tw_num_levels", "tw_stage_pyr_level",
+    "tw_stage_polyexp", "tw_stage_update_matrices", "tw_stage_flow_upsample_update", "tw_stage_blur_solve",
+]
+
+
+def lib():
+    """Load libtwflow.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("libtwflow.so not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    L = C.CDLL(LIB_PATH)
+    vp, fp, u8p, ip = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_uint8), C.POINTER(C.c_int)
+    L.tw_default_params.argtypes = [C.POINTER(Params)]
+    L.tw_default_params.restype = None
+    L.tw_device_count.restype = C.c_int
+    L.tw_engine_create.argtypes = [C.c_int, C.POINTER(Params), C.c_int, C.POINTER(vp)]
+    L.tw_engine_destroy.argtypes = [vp]
+    L.tw_engine_destroy.restype = None
+    L.tw_strerror.argtypes = [C.c_int]
+    L.tw_strerror.restype = C.c_char_p
+    L.tw_last_error.argtypes = [vp]
+    L.tw_last_error.restype = C.c_char_p
+    L.tw_flow_u8.argtypes = [vp, u8p, u8p, C.c_int, C.c_int, C.c_ssize_t, fp, fp, fp]
+    L.tw_diff_u8.argtypes = [vp, u8p, u8p, C.c_int, C.c_int, C.c_ssize_t, C.c_int, C.c_double,
+                             C.POINTER(Vector), C.c_int, ip, fp]
+    L.tw_submit_u8.argtypes = [vp, u8p, u8p, C.c_int, C.c_int, C.c_ssize_t, C.c_int, C.c_double,
+                               C.POINTER(C.c_int64)]
+    L.tw_submit_dev.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_ssize_t, C.c_int, C.c_double,
+                                C.POINTER(C.c_int64)]
+    L.tw_wait.argtypes = [vp, C.c_int64, C.POINTER(Vector), C.c_int, ip, fp]
+    L.tw_grid_capacity.argtypes = [C.c_int, C.c_int, C.c_int]
+    L.tw_dev_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
+    L.tw_dev_free.argtypes = [vp, vp]
+    L.tw_dev_upload.argtypes = [vp, vp, vp, C.c_size_t]
+    L.tw_prof_select.argtypes = [vp, C.c_int, C.c_int]
+    L.tw_prof_read.argtypes = [vp, C.POINTER(C.c_double), ip]
+    L.tw_algorithmic_bytes.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.tw_algorithmic_bytes.restype = C.c_double
+    L.tw_algorithmic_bytes_pair.argtypes = [vp, C.c_int, C.c_int, C.c_int]
+    L.tw_algorithmic_bytes_pair.restype = C.c_double
+    L.tw_num_levels.argtypes = [vp, C.c_int, C.c_int]
+    L.tw_stage_pyr_level.argtypes = [vp, u8p, C.c_int, C.c_int, C.c_int, fp, ip, ip]
+    L.tw_stage_polyexp.argtypes = [vp, fp, C.c_int, C.c_int, fp]
+    L.tw_stage_update_matrices.argtypes = [vp, fp, fp, fp, C.c_int, C.c_int, fp]
+    L.tw_stage_flow_upsample_update.argtypes = [vp, fp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, fp, fp]
+    L.tw_stage_blur_solve.argtypes = [vp, fp, fp, fp, C.c_int, C.c_int, C.c_int, fp, fp]
+    _lib = L
+    return L
+
+
+def default_params(**kw):
+    p = Params()
+    lib().tw_default_params(C.byref(p))
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def device_count():
+    return lib().tw_device_count()
+
+
+def grid_capacity(w, h, span):
+    return lib().tw_grid_capacity(w, h, span)
+
+
+def _f(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _u8(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint8))
+
+
+def _gray(a):
+    a = np.asarray(a)
+    if a.dtype != np.uint8 or a.ndim != 2:
+        raise TwError(TW_E_BAD_IMAGE_FORMAT, "expected a 2-D uint8 image")
+    if a.strides[1] != 1:
+        a = np.ascontiguousarray(a)
+    return a
+
+
+class Engine:
+    """One worker's engine on one GPU (OpticalFlowByGPU of the reference, src/opticalflow.h:62-70)."""
+
+    def __init__(self, device=0, params=None, slots=1):
+        self._L = lib()
+        self._h = C.c_void_p()
+        self.params = params or default_params()
+        rc = self._L.tw_engine_create(device, C.byref(self.params), slots, C.byref(self._h))
+        if rc != TW_OK:
+            self._h = C.c_void_p()
+            raise TwError(rc, self._L.tw_strerror(rc).decode())
+        self.device = device
+        self.slots = slots
+        self._devbufs = []
+
+    def close(self):
+        if self._h:
+            for d in self._devbufs:
+                self._L.tw_dev_free(self._h, d)
+            self._devbufs = []
+            self._L.tw_engine_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, rc):
+        if rc != TW_OK:
+            msg = self._L.tw_last_error(self._h).decode() or self._L.tw_strerror(rc).decode()
+            raise TwError(rc, msg)
+
+    # ---- OpticalFlow::calculateInternal -------------------------------------------------------------
+    def calculate_internal(self, expect, target):
+        """Returns (flowx, flowy, seconds)."""
+        a, b = _gray(expect), _gray(target)
+        if a.shape != b.shape:
+            raise TwError(TW_E_DONT_MATCH_SIZE, "Don't match image size")
+        h, w = a.shape
+        fx = np.empty((h, w), np.float32)
+        fy = np.empty((h, w), np.float32)
+        sec = C.c_float()
+        if a.strides[0] != b.strides[0]:
+            a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+        self._check(self._L.tw_flow_u8(self._h, _u8(a), _u8(b), w, h, a.strides[0], _f(fx), _f(fy), C.byref(sec)))
+        return fx, fy, sec.value
+
+    # ---- flow + span-grid scan ---------------------------------------------------------------------
+    def diff(self, expect, target, span=10, threshold=5.0):
+        """Returns dict(status, vector=[(x,y,dx,dy)...], time, height, width) like Response."""
+        t = self.submit(expect, target, span, threshold)
+        return self.wait(t)
+
+    def submit(self, expect, target, span=10, threshold=5.0):
+        a, b = _gray(expect), _gray(target)
+        if a.shape != b.shape:
+            raise TwError(TW_E_DONT_MATCH_SIZE, "Don't match image size")
+        if a.strides[0] != b.strides[0]:
+            a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+        h, w = a.shape
+        tk = C.c_int64()
+        self._check(self._L.tw_submit_u8(self._h, _u8(a), _u8(b), w, h, a.strides[0], span, threshold, C.byref(tk)))
+        return (tk.value, w, h, span, threshold)
+
+    def submit_dev(self, d_expect, d_target, w, h, stride, span=10, threshold=5.0):
+        tk = C.c_int64()
+        self._check(self._L.tw_submit_dev(self._h, d_expect, d_target, w, h, stride, span, threshold, C.byref(tk)))
+        return (tk.value, w, h, span, threshold)
+
+    def wait(self, ticket):
+        tk, w, h, span, threshold = ticket
+        cap = max(self._L.tw_grid_capacity(w, h, span), 1)
+        out = (Vector * cap)()
+        n = C.c_int()
+        sec = C.c_float()
+        self._check(self._L.tw_wait(self._h, tk, out, cap, C.byref(n), C.byref(sec)))
+        vec = [(out[i].x, out[i].y, out[i].dx, out[i].dy) for i in range(n.value)]
+        return {"status": "OK" if n.value == 0 else "SUSPICIOUS", "span": span, "threshold": threshold,
+                "time": sec.value, "height": h, "width": w, "vector": vec}
+
+    def wait_count(self, ticket):
+        """tw_wait without materialising the vectors (bench inner loop). Returns (n, seconds)."""
+        tk = ticket[0]
+        n = C.c_int()
+        sec = C.c_float()
+        self._check(self._L.tw_wait(self._h, tk, None, 0, C.byref(n), C.byref(sec)))
+        return n.value, sec.value
+
+    # ---- device memory --------------------------------------------------------------------------------
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        d = C.c_void_p()
+        self._check(self._L.tw_dev_alloc(self._h, arr.nbytes, C.byref(d)))
+        self._devbufs.append(d)
+        self._check(self._L.tw_dev_upload(self._h, d, arr.ctypes.data_as(C.c_void_p), arr.nbytes))
+        return d
+
+    # ---- instrumentation -------------------------------------------------------------------------------
+    def prof_select(self, kclass, level=-1):
+        self._check(self._L.tw_prof_select(self._h, kclass, level))
+
+    def prof_read(self):
+        ms = C.c_double()
+        n = C.c_int()
+        self._check(self._L.tw_prof_read(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def algorithmic_bytes(self, kclass, level, w, h):
+        return self._L.tw_algorithmic_bytes(self._h, kclass, level, w, h)
+
+    def algorithmic_bytes_pair(self, w, h, span):
+        return self._L.tw_algorithmic_bytes_pair(self._h, w, h, span)
+
+    def num_levels(self, w, h):
+        return self._L.tw_num_levels(self._h, w, h)
+
+    # ---- per-stage entry points (planar layouts) ----------------------------------------------------
+    def stage_pyr_level(self, img, level):
+        img = np.ascontiguousarray(_gray(img))
+        h0, w0 = img.shape
+        buf = np.empty(h0 * w0, np.float32)
+        w, h = C.c_int(), C.c_int()
+        self._check(self._L.tw_stage_pyr_level(self._h, _u8(img), w0, h0, level, _f(buf), C.byref(w), C.byref(h)))
+        return buf[: w.value * h.value].reshape(h.value, w.value).copy()
+
+    def stage_polyexp(self, I):
+        I = np.ascontiguousarray(I, np.float32)
+        h, w = I.shape
+        R = np.empty((5, h, w), np.float32)
+        self._check(self._L.tw_stage_polyexp(self._h, _f(I), w, h, _f(R)))
+        return R
+
+    def stage_update_matrices(self, R0, R1, flow):
+        R0 = np.ascontiguousarray(R0, np.float32)
+        R1 = np.ascontiguousarray(R1, np.float32)
+        flow = np.ascontiguousarray(flow, np.float32)
+        _, h, w = R0.shape
+        M = np.empty((5, h, w), np.float32)
+        self._check(self._L.tw_stage_update_matrices(self._h, _f(R0), _f(R1), _f(flow), w, h, _f(M)))
+        return M
+
+    def stage_flow_upsample_update(self, R0, R1, prevflow):
+        R0 = np.ascontiguousarray(R0, np.float32)
+        R1 = np.ascontiguousarray(R1, np.float32)
+        prevflow = np.ascontiguousarray(prevflow, np.float32)
+        _, h, w = R0.shape
+        _, ph, pw = prevflow.shape
+        flow = np.empty((2, h, w), np.float32)
+        M = np.empty((5, h, w), np.float32)
+        self._check(self._L.tw_stage_flow_upsample_update(self._h, _f(R0), _f(R1), _f(prevflow), pw, ph, w, h,
+                                                          _f(flow), _f(M)))
+        return flow, M
+
+    def stage_blur_solve(self, R0, R1, M, update_matrices):
+        R0 = np.ascontiguousarray(R0, np.float32)
+        R1 = np.ascontiguousarray(R1, np.float32)
+        M = np.ascontiguousarray(M, np.float32)
+        _, h, w = R0.shape
+        flow = np.empty((2, h, w), np.float32)
+        Mo = np.empty((5, h, w), np.float32)
+        self._check(self._L.tw_stage_blur_solve(self._h, _f(R0), _f(R1), _f(M), w, h, int(bool(update_matrices)),
+                                                _f(flow), _f(Mo)))
+        return flow, (Mo if update_matrices else None)
