@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""bench.py — image-pairs/sec @1080p Farneback (default params) on N MI355X.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 it is launched through
+torch.distributed.run, one rank per GPU.  One "step" = one pass of the hot path over one batch of
+BATCH synthetic 1920x1080 pairs that are already resident in HBM when the timed region starts (BASELINE.json
+config "batch of 1080p pairs, 1xMI355X"; the single-pair latency of configs[1] is reported beside it).
+Pairs shard embarrassingly across ranks (weak scaling: every rank processes its own batch); there is no
+data-path collective — torch.distributed (RCCL) is used only for the barrier and the max-over-ranks of
+the elapsed time.
+
+The JSON line also carries
+  roofline      dominant kernel (tw_blur_solve @ level 0): algorithmic bytes per launch / hipEvent-measured
+                average launch duration inside the timed region, vs the 8.0 TB/s HBM3E peak
+  roofline_polyexp   the same for tw_polyexp @ level 0 (the kernel BASELINE.json grades)
+  cpu_baseline  the CPU oracle (a scalar port of OpenCV 2.4.9's algorithm; OpenCV itself is not
+                installable here) timed on this box's host cores on a bounded sample — rank 0, N=1 only
+The oracle is used here only as the cpu_baseline leg and to check one result; it is never the thing
+measured as `value`.
+"""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "tidal-wave_amd"))
+
+import numpy as np  # noqa: E402
+
+W, H = 1920, 1080
+SPAN, THRESHOLD = 10, 5.0
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable copy rate)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=64, help="1080p pairs per step per GPU")
+    ap.add_argument("--slots", type=int, default=8, help="pairs in flight per GPU (HIP streams)")
+    ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic pairs cycled through")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prof", action="store_true", help="no per-kernel hipEvents in the timed region")
+    ap.add_argument("--cpu-pairs", type=int, default=0, help="pairs in the CPU sample (0: one per thread)")
+    return ap.parse_args()
+
+
+def cpu_baseline(pairs):
+    """The reference's CPU driving pattern (src/manager.cpp:55-59: numThreads consumers on one queue, each
+    computing one pair at a time single-threaded) with the oracle standing in for OpenCV."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as O
+    O.build()
+    O.lib()
+    cores = os.cpu_count() or 1
+    threads = min(cores, 16)
+    njobs = threads
+    jobs = list(range(njobs))
+    lock = threading.Lock()
+    out = {}
+
+    def work():
+        while True:
+            with lock:
+                if not jobs:
+                    return
+                j = jobs.pop()
+            a, b = pairs[j % len(pairs)]
+            fx, fy = O.farneback(a, b)  # ctypes releases the GIL
+            out[j] = O.span_scan(fx, fy, SPAN, THRESHOLD)
+
+    t0 = time.perf_counter()
+    th = [threading.Thread(target=work) for _ in range(threads)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    dt = time.perf_counter() - t0
+    return {"value": njobs / dt, "unit": "pairs/s", "cores": threads, "kind": "port",
+            "sample": "%d x 1920x1080 synthetic pairs, one per thread, %d threads of %d host cores, %.1f s wall"
+                      % (njobs, threads, cores, dt)}, out
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+
+    import synth
+    import twflow
+
+    if twflow.device_count() < 1:
+        raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
+    eng = twflow.Engine(local_rank, twflow.default_params(), slots=args.slots)
+
+    # synthetic pairs: the same seeds on every rank (weak scaling: each rank owns its batch)
+    host_pairs = [synth.make_pair(i, H, W) for i in range(args.distinct)]
+    dev_pairs = [(eng.upload(a), eng.upload(b)) for a, b in host_pairs]
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    flagged = [0]
+
+    def step():
+        inflight = []
+        for j in range(args.batch):
+            if len(inflight) == args.slots:
+                n, _ = eng.wait_count(inflight.pop(0))
+                flagged[0] += n
+            da, db = dev_pairs[j % len(dev_pairs)]
+            inflight.append(eng.submit_dev(da, db, W, H, W, SPAN, THRESHOLD))
+        while inflight:
+            n, _ = eng.wait_count(inflight.pop(0))
+            flagged[0] += n
+
+    # single-pair latency (configs[1]) and a result check before timing
+    res0 = eng.diff(host_pairs[0][0], host_pairs[0][1], SPAN, THRESHOLD)
+    lat = []
+    for _ in range(5):
+        r = eng.wait(eng.submit_dev(dev_pairs[0][0], dev_pairs[0][1], W, H, W, SPAN, THRESHOLD))
+        lat.append(r["time"])
+    assert r["vector"] == res0["vector"]
+
+    for _ in range(args.warmup):
+        step()
+    if not args.no_prof:
+        eng.prof_select(twflow.K_BLUR_SOLVE, 0)
+        eng.prof_select(twflow.K_POLYEXP, 0)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    prof = {}
+    if not args.no_prof:
+        for kc in (twflow.K_BLUR_SOLVE, twflow.K_POLYEXP):
+            ms, n = eng.prof_read(kc)
+            prof[kc] = (ms, n)
+        eng.prof_select(-1, -2)
+
+    if rank == 0:
+        pairs_total = args.batch * args.steps * world
+        value = pairs_total / elapsed
+        bytes_pair = eng.algorithmic_bytes_pair(W, H, SPAN)
+        traffic = {}
+        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath))
+            except Exception:
+                traffic = {}
+
+        def roof(kc):
+            if kc not in prof or prof[kc][1] == 0:
+                return None
+            ms, n = prof[kc]
+            bytes_launch = eng.algorithmic_bytes(kc, 0, W, H)
+            gbs = bytes_launch / (ms / n * 1e-3) / 1e9
+            name = twflow.KERNEL_NAMES[kc]
+            return {"kernel": name + " @level0 (1920x1080)", "bound": "hbm", "achieved": round(gbs, 1),
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                    "traffic": traffic.get(name), "algorithmic_bytes_per_launch": bytes_launch,
+                    "avg_launch_us": round(ms / n * 1e3, 2), "launches": n,
+                    "note": "hipEvent duration inside the timed region, %d streams in flight" % args.slots}
+
+        line = {
+            "metric": "image-pairs/sec @1080p Farneback (default params), 1/2/4/8 MI355X",
+            "value": round(value, 2), "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "batch of %d x 1920x1080 u8 gray pairs per GPU per step, resident in HBM, "
+                                   "default params (pyrScale 0.5, pyrLevels 3, winSize 30, iters 3, polyN 7, "
+                                   "polySigma 1.5, Gaussian window), span 10, threshold 5" % args.batch,
+                       "batch_per_gpu": args.batch, "pairs_in_flight_per_gpu": args.slots,
+                       "parallelism": "pairs sharded over %d GPU(s), no collective" % world,
+                       "single_pair_latency_ms": round(float(np.median(lat)) * 1e3, 4)},
+            "pair_roofline": {"algorithmic_bytes_per_pair": bytes_pair,
+                              "achieved_GBps_per_gpu": round(bytes_pair * value / world / 1e9, 1),
+                              "frac_of_8TBps": round(bytes_pair * value / world / 1e9 / HBM_PEAK_GBS, 4)},
+            "roofline": roof(twflow.K_BLUR_SOLVE),
+            "roofline_polyexp": roof(twflow.K_POLYEXP),
+            "flagged_vectors": flagged[0],
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            cb, cpu_out = cpu_baseline(host_pairs)
+            line["cpu_baseline"] = cb
+            # the GPU answer for pair 0 equals the oracle's (vector list, bit for bit)
+            line["cpu_baseline"]["gpu_matches_oracle_on_pair0"] = bool(cpu_out.get(0) == res0["vector"]) \
+                if 0 in cpu_out else None
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+
+    eng.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -126,11 +126,13 @@ enum {
     TW_K_COUNT = 5
 };
 
-/* Every later launch of kernel class `kclass` (-1: timing off) at pyramid level `level` (-1: every
- * level) is bracketed by hipEvents on the stream it is launched on; totals accumulate until read. */
+/* Every later launch of kernel class `kclass` at pyramid level `level` (-1: every level, -2: off) is
+ * bracketed by hipEvents on the stream it is launched on; several classes may be on at once;
+ * kclass -1 turns all of them off.  Totals accumulate per class until read. */
 tw_status tw_prof_select(tw_engine* e, int kclass, int level);
-/* Sum of event-measured milliseconds and number of launches since the last call; resets both. */
-tw_status tw_prof_read(tw_engine* e, double* ms_total, int* launches);
+/* Sum of event-measured milliseconds and number of launches of `kclass` since the last read; resets both.
+ * Synchronises the device. */
+tw_status tw_prof_read(tw_engine* e, int kclass, double* ms_total, int* launches);
 /* Algorithmic bytes (SURVEY §8d model) of one launch of `kclass` at `level` for a w x h pair. */
 double tw_algorithmic_bytes(const tw_engine* e, int kclass, int level, int width, int height);
 /* Algorithmic bytes of one whole pair (sum over levels and stages, scan included). */

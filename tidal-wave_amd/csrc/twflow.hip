@@ -269,9 +269,9 @@ struct tw_engine {
     int win_m = 15;
     std::string err;
     int next_slot = 0;
-    // profiling
-    int prof_class = -1, prof_level = -1;
-    std::vector<ProfPair> prof_pending;
+    // profiling: per kernel class, -2 = off, -1 = every level, k = level k only
+    int prof_level[TW_K_COUNT] = {-2, -2, -2, -2, -2};
+    std::vector<ProfPair> prof_pending[TW_K_COUNT];
     std::vector<hipEvent_t> prof_free;
 };
 
@@ -465,10 +465,11 @@ struct ProfScope {
     tw_engine* e;
     hipStream_t st;
     bool on;
+    int kc;
     ProfPair pp;
-    ProfScope(tw_engine* e_, hipStream_t st_, int kclass, int level) : e(e_), st(st_)
+    ProfScope(tw_engine* e_, hipStream_t st_, int kclass, int level) : e(e_), st(st_), kc(kclass)
     {
-        on = (e->prof_class == kclass && (e->prof_level < 0 || e->prof_level == level));
+        on = (e->prof_level[kclass] == -1 || (e->prof_level[kclass] >= 0 && e->prof_level[kclass] == level));
         if (on) {
             pp.a = prof_event(e);
             pp.b = prof_event(e);
@@ -479,7 +480,7 @@ struct ProfScope {
     {
         if (on) {
             (void)hipEventRecord(pp.b, st);
-            e->prof_pending.push_back(pp);
+            e->prof_pending[kc].push_back(pp);
         }
     }
 };
@@ -846,10 +847,11 @@ void tw_engine_destroy(tw_engine* e)
         for (void* d : kv.second->owned) (void)hipFree(d);
         delete kv.second;
     }
-    for (ProfPair& pp : e->prof_pending) {
-        (void)hipEventDestroy(pp.a);
-        (void)hipEventDestroy(pp.b);
-    }
+    for (auto& pend : e->prof_pending)
+        for (ProfPair& pp : pend) {
+            (void)hipEventDestroy(pp.a);
+            (void)hipEventDestroy(pp.b);
+        }
     for (hipEvent_t ev : e->prof_free) (void)hipEventDestroy(ev);
     delete e;
 }
@@ -973,19 +975,22 @@ tw_status tw_dev_upload(tw_engine* e, void* dptr, const void* host, size_t bytes
 tw_status tw_prof_select(tw_engine* e, int kclass, int level)
 {
     if (!e || kclass >= TW_K_COUNT) return TW_E_BAD_PARAMETER;
-    e->prof_class = kclass;
-    e->prof_level = level;
+    if (kclass < 0) {
+        for (int i = 0; i < TW_K_COUNT; i++) e->prof_level[i] = -2;
+        return TW_OK;
+    }
+    e->prof_level[kclass] = level < -1 ? -2 : level;
     return TW_OK;
 }
 
-tw_status tw_prof_read(tw_engine* e, double* ms_total, int* launches)
+tw_status tw_prof_read(tw_engine* e, int kclass, double* ms_total, int* launches)
 {
-    if (!e) return TW_E_BAD_PARAMETER;
+    if (!e || kclass < 0 || kclass >= TW_K_COUNT) return TW_E_BAD_PARAMETER;
     TW_HIP(e, hipSetDevice(e->device));
     TW_HIP(e, hipDeviceSynchronize());
     double tot = 0;
     int cnt = 0;
-    for (ProfPair& pp : e->prof_pending) {
+    for (ProfPair& pp : e->prof_pending[kclass]) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, pp.a, pp.b) == hipSuccess) {
             tot += ms;
@@ -994,7 +999,7 @@ tw_status tw_prof_read(tw_engine* e, double* ms_total, int* launches)
         e->prof_free.push_back(pp.a);
         e->prof_free.push_back(pp.b);
     }
-    e->prof_pending.clear();
+    e->prof_pending[kclass].clear();
     if (ms_total) *ms_total = tot;
     if (launches) *launches = cnt;
     return TW_OK;

@@ -85,7 +85,7 @@ def lib():
     L.tw_dev_free.argtypes = [vp, vp]
     L.tw_dev_upload.argtypes = [vp, vp, vp, C.c_size_t]
     L.tw_prof_select.argtypes = [vp, C.c_int, C.c_int]
-    L.tw_prof_read.argtypes = [vp, C.POINTER(C.c_double), ip]
+    L.tw_prof_read.argtypes = [vp, C.c_int, C.POINTER(C.c_double), ip]
     L.tw_algorithmic_bytes.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int]
     L.tw_algorithmic_bytes.restype = C.c_double
     L.tw_algorithmic_bytes_pair.argtypes = [vp, C.c_int, C.c_int, C.c_int]
@@ -242,10 +242,10 @@ class Engine:
     def prof_select(self, kclass, level=-1):
         self._check(self._L.tw_prof_select(self._h, kclass, level))
 
-    def prof_read(self):
+    def prof_read(self, kclass):
         ms = C.c_double()
         n = C.c_int()
-        self._check(self._L.tw_prof_read(self._h, C.byref(ms), C.byref(n)))
+        self._check(self._L.tw_prof_read(self._h, kclass, C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
     def algorithmic_bytes(self, kclass, level, w, h):
