@@ -72,8 +72,7 @@ void tw_default_params(tw_params* p);
 int tw_device_count(void);
 
 /* new OpticalFlowByGPU() + cv::gpu::setDevice(id), src/consumer.cpp:21-30.
- * `slots` = image pairs that may be in flight at once on this engine (>= 1; each owns a HIP stream
- * and a workspace).  Parameters are fixed per engine like Consumer::parameter (src/consumer.cpp:97). */
+ * `slots` = image pairs per batch (>= 1); up to three batches may be outstanding.  Parameters are fixed per engine like Consumer::parameter (src/consumer.cpp:97). */
 tw_status tw_engine_create(int device, const tw_params* params, int slots, tw_engine** out);
 void tw_engine_destroy(tw_engine* e);
 
@@ -104,6 +103,11 @@ tw_status tw_submit_u8(tw_engine* e, const uint8_t* expect, const uint8_t* targe
 /* Same with the images already resident in device memory (HBM) of the engine's device. */
 tw_status tw_submit_dev(tw_engine* e, const void* d_expect, const void* d_target, int width, int height,
                         ptrdiff_t stride, int span, double threshold, tw_ticket* ticket);
+/* Submitted pairs are gathered into a batch of up to `slots` pairs and executed together, level by level
+ * (every kernel launch covers as many pairs as it takes to fill the GPU).  A batch starts executing when it
+ * is full, when tw_flush is called, or when one of its tickets is waited for.  `seconds` of a pair is the
+ * device time of its batch divided by the pairs in it (exact for a batch of one). */
+tw_status tw_flush(tw_engine* e);
 tw_status tw_wait(tw_engine* e, tw_ticket ticket, tw_vector* out, int cap, int* n, float* seconds);
 
 /* Number of grid points ceil(h/span)*ceil(w/span): the capacity that can never overflow. */
@@ -139,6 +143,15 @@ double tw_algorithmic_bytes(const tw_engine* e, int kclass, int level, int width
 double tw_algorithmic_bytes_pair(const tw_engine* e, int width, int height, int span);
 /* Number of pyramid levels (= index of the coarsest level) the engine uses for w x h. */
 int tw_num_levels(const tw_engine* e, int width, int height);
+/* Image pairs one kernel launch covers at `level` (the level-major batch schedule), -1 on error. */
+int tw_level_chunk(tw_engine* e, int width, int height, int level);
+
+/* Isolated timing of one kernel class at `level` of a width x height pair, `npairs` pairs per launch, on
+ * synthetic device-resident data: average microseconds per launch over `iters` back-to-back launches
+ * (hipEvents on the engine's stream).  flags: 1 = rough (non-smooth) flow field, 2 = tw_blur_solve without
+ * the fused matrix refresh. */
+tw_status tw_bench_stage(tw_engine* e, int kclass, int width, int height, int level, int npairs, int iters,
+                         int flags, float* avg_us);
 
 /* ---- per-stage entry points (parity tests; host buffers, synchronous) --------------------------------
  * Layouts: images/planes are dense row-major; R and M are 5 planes [5][h][w]; flow is 2 planes. */

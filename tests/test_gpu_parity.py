@@ -174,25 +174,57 @@ def test_1080p_one_pair_against_oracle(engine, oracle):
 
 
 def test_1080p_properties_batch(twflow):
-    """Size-independent properties at the bench's full size, several pairs in flight (config[2] shape):
-    identical pairs report nothing; submission order and slot reuse do not change any result."""
+    """Size-independent properties at the bench's full size with batches in flight (config[2] shape):
+    identical pairs report nothing; batching, submission order and context reuse change no result."""
     import synth
-    with twflow.Engine(0, twflow.default_params(), slots=3) as e:
+    with twflow.Engine(0, twflow.default_params(), slots=2) as e:
         pairs = [synth.make_pair(i, 1080, 1920) for i in (2, 3)]
         single = [e.diff(a, b) for a, b in pairs]
         assert single[1]["status"] == "OK"           # identical pair (kind 3)
         assert single[0]["status"] == "SUSPICIOUS"   # painted rectangle
-        tickets = [e.submit(*pairs[i % 2]) for i in range(3)]
-        with pytest.raises(twflow.TwError) as ei:   # all three slots busy
+        tickets = [e.submit(*pairs[i % 2]) for i in range(6)]   # three full batches of two
+        with pytest.raises(twflow.TwError) as ei:   # every batch context still owes results
             e.submit(*pairs[0])
         assert ei.value.code == twflow.TW_E_BUSY
-        out = [e.wait(t) for t in tickets]
-        for i, r in enumerate(out):
+        out = [e.wait(t) for t in reversed(tickets)]
+        for i, r in zip(reversed(range(6)), out):
             assert r["vector"] == single[i % 2]["vector"]
+        # a partial batch runs when one of its tickets is waited for
+        t = e.submit(*pairs[1])
+        assert e.wait(t)["vector"] == []
         # resident-in-HBM inputs give the same answer as host inputs
         da, db = e.upload(pairs[0][0]), e.upload(pairs[0][1])
         r = e.wait(e.submit_dev(da, db, 1920, 1080, 1920))
         assert r["vector"] == single[0]["vector"]
+
+
+def test_batched_mixed_sizes_and_order(twflow, oracle):
+    """Pairs of different sizes interleaved: each size change closes a batch; results keep their tickets."""
+    rng = np.random.default_rng(9)
+    with twflow.Engine(0, twflow.default_params(), slots=4) as e:
+        jobs = []
+        # three batches (the engine keeps at most three outstanding): [117x180 x2], [257x333], [64x64 x3]
+        for i, (h, w) in enumerate([(117, 180), (117, 180), (257, 333), (64, 64), (64, 64), (64, 64)]):
+            a = rand_img(rng, h, w)
+            b = np.roll(a, 1 + i % 3, axis=1)
+            jobs.append((a, b, e.submit(a, b, 10, 0.5)))
+        for a, b, t in jobs:
+            wx, wy = oracle.farneback(a, b)
+            assert e.wait(t)["vector"] == oracle.span_scan(wx, wy, 10, 0.5)
+
+
+def test_scan_many_hits_and_dense_span(twflow, oracle):
+    """More hits than the eager 1024-record copy, and span 1 (every pixel is a grid point)."""
+    rng = np.random.default_rng(4)
+    a = rand_img(rng, 120, 160)
+    b = np.roll(a, 3, axis=1)
+    wx, wy = oracle.farneback(a, b)
+    with twflow.Engine(0, twflow.default_params(), slots=1) as e:
+        for span, thr in [(1, 0.25), (2, 0.0), (3, 1.0), (7, 0.5)]:
+            want = oracle.span_scan(wx, wy, span, thr)
+            got = e.diff(a, b, span, thr)["vector"]
+            assert len(want) > (1024 if span <= 2 else 0)
+            assert got == want
 
 
 @pytest.mark.parametrize("kw", [dict(polyN=5, polySigma=1.1), dict(winSize=50, pyrIterations=2),

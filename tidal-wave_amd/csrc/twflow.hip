@@ -212,6 +212,7 @@ struct LevelPlan {
     long long ps = 0;  // plane stride (elements)
     double sigma = 0, scale = 1;
     int ksize = 3;
+    int chunk = 1;  // image pairs per launch at this level (sized to fill the chip)
     // pyramid tables (full-res -> level)
     int *d_xofs = nullptr, *d_yofs = nullptr;
     float *d_alpha = nullptr, *d_beta = nullptr, *d_kern = nullptr;
@@ -229,28 +230,33 @@ struct Plan {
     std::vector<void*> owned;  // device allocations
 };
 
-struct Slot {
-    hipStream_t stream = nullptr;
-    hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_done = nullptr;
-    // workspace
-    size_t cap_px = 0;  // ld0*h0 capacity
-    uint8_t* d_img = nullptr;
-    size_t img_cap = 0;
-    uint8_t* h_img = nullptr;  // pinned staging
-    float *I[2] = {nullptr, nullptr}, *R[2] = {nullptr, nullptr}, *M[2] = {nullptr, nullptr},
-          *flow[2] = {nullptr, nullptr};
-    int* d_count = nullptr;
-    ScanRec* d_rec = nullptr;
-    size_t rec_cap = 0;
-    int* h_count = nullptr;  // pinned: [0]=count, then ScanRec[HOST_RECS]
-    // state
-    bool busy = false;
-    int64_t gen = 0;
-    int w = 0, h = 0, span = 0;
-    int final_flow = 0;
+constexpr int HOST_RECS = 1024;  // flagged vectors per pair copied back eagerly
+constexpr int NCTX = 3;          // batches that may be in flight (host-side state only)
+
+struct Job {
+    const uint8_t *h_a = nullptr, *h_b = nullptr;  // host inputs already staged (null for device inputs)
+    const uint8_t *d_a = nullptr, *d_b = nullptr;
+    long long stride = 0;
+    bool waited = false;
 };
 
-constexpr int HOST_RECS = 1024;
+// One batch of pairs: host-side state that must outlive the asynchronous execution.
+struct Ctx {
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_done = nullptr;
+    std::vector<Job> jobs;
+    int64_t first_ticket = 0;
+    bool launched = false;
+    int pending = 0;  // jobs not yet waited
+    int w = 0, h = 0, span = 0;
+    double threshold = 0;
+    bool any_host = false;
+    // pinned host memory
+    uint8_t* h_img = nullptr;
+    size_t h_img_cap = 0;
+    const uint8_t** h_ptrs = nullptr;  // [2*cap]
+    int* h_count = nullptr;            // [cap]
+    ScanRec* h_rec = nullptr;          // [cap][HOST_RECS]
+};
 
 struct ProfPair {
     hipEvent_t a, b;
@@ -261,14 +267,28 @@ struct ProfPair {
 struct tw_engine {
     int device = 0;
     tw_params p;
-    int nslots = 1;
-    std::vector<Slot> slots;
+    int cap = 1;  // pairs per batch ("slots")
+    hipStream_t stream = nullptr;
+    Ctx ctx[NCTX];
+    int cur = 0;  // context accepting submissions
+    int64_t next_ticket = 1;
     std::map<std::pair<int, int>, Plan*> plans;
     PolyCoef pc;
     WinCoef wc;
     int win_m = 15;
+    int blur_variant = 5;  // 5: v3 structure with the refresh fused into the solve phase (default); 4: v3 + separate refresh; 0-3: earlier structures kept for A/B
     std::string err;
-    int next_slot = 0;
+    // device workspace, shared by all batches (execution is ordered on one stream)
+    size_t ws_elems = 0;                 // capacity of I (floats); R = 5x, M = 5x each
+    float *I = nullptr, *R = nullptr, *M[2] = {nullptr, nullptr};
+    std::vector<float*> flow;            // per level, cap (levels>=1) or chunk0 (level 0) pairs x 2 planes
+    std::vector<size_t> flow_cap;
+    uint8_t* d_img = nullptr;
+    size_t d_img_cap = 0;
+    const uint8_t** d_ptrs = nullptr;  // [2*cap]
+    int* d_count = nullptr;            // [cap]
+    ScanRec* d_rec = nullptr;          // [cap][G]
+    size_t d_rec_cap = 0;
     // profiling: per kernel class, -2 = off, -1 = every level, k = level k only
     int prof_level[TW_K_COUNT] = {-2, -2, -2, -2, -2};
     std::vector<ProfPair> prof_pending[TW_K_COUNT];
@@ -336,6 +356,12 @@ int pyr_nrows_max(const ResizeTab& t, int h, int h0, int r)
     return mx;
 }
 
+void free_plan(Plan* pl)
+{
+    for (void* d : pl->owned) (void)hipFree(d);
+    delete pl;
+}
+
 tw_status get_plan(tw_engine* e, int w0, int h0, Plan** out)
 {
     auto key = std::make_pair(w0, h0);
@@ -355,11 +381,17 @@ tw_status get_plan(tw_engine* e, int w0, int h0, Plan** out)
         level_geometry(w0, h0, e->p.pyrScale, k, &L.w, &L.h, &L.sigma, &L.ksize, &L.scale);
         if (L.w < 1 || L.h < 1 || L.ksize > PYR_MAXK - 1) {
             e->err = "pyramid level degenerate or smoothing kernel too large";
-            delete pl;
+            free_plan(pl);
             return TW_E_UNSUPPORTED;
         }
         L.ld = round_up(L.w, 32);
         L.ps = (long long)L.ld * L.h;
+        // pairs per launch: enough 8-row x 240-column tiles of two images to cover the 256 CUs ~8x over
+        const long long tiles = (long long)((L.w + PE_TW - 1) / PE_TW) * ((L.h + PE_TH - 1) / PE_TH) * 2;
+        long long target = 4096;
+        if (const char* ev = getenv("TW_CHUNK_TILES")) target = std::max(1, atoi(ev));
+        long long c = (target + tiles - 1) / tiles;
+        L.chunk = (int)std::min<long long>(std::max<long long>(c, 1), e->cap);
     }
     for (int k = 0; k <= pl->levels; k++) {
         LevelPlan& L = pl->lv[k];
@@ -373,15 +405,16 @@ tw_status get_plan(tw_engine* e, int w0, int h0, Plan** out)
         const size_t lds = (size_t)(PYR_MAXK + (size_t)L.nrows_max * (t.mode == 0 ? PYR_TW : 2 * PYR_TW)) * 4;
         if (lds > 160 * 1024) {
             e->err = "pyramid tile does not fit LDS (scale/kernel too large)";
-            for (void* d : pl->owned) (void)hipFree(d);
-            delete pl;
+            free_plan(pl);
             return TW_E_UNSUPPORTED;
         }
         tw_status s;
         if ((s = upload_vec(e, pl, t.xofs, &L.d_xofs)) || (s = upload_vec(e, pl, t.yofs, &L.d_yofs)) ||
             (s = upload_vec(e, pl, t.alpha, &L.d_alpha)) || (s = upload_vec(e, pl, t.beta, &L.d_beta)) ||
-            (s = upload_vec(e, pl, kern, &L.d_kern)))
+            (s = upload_vec(e, pl, kern, &L.d_kern))) {
+            free_plan(pl);
             return s;
+        }
         if (k < pl->levels) {
             const LevelPlan& P = pl->lv[k + 1];
             ResizeTab u;
@@ -389,12 +422,15 @@ tw_status get_plan(tw_engine* e, int w0, int h0, Plan** out)
             if (u.mode == 2) {
                 // cannot happen for pyr_scale < 1 (the previous level is never twice as large)
                 e->err = "unexpected area-fast flow resize";
+                free_plan(pl);
                 return TW_E_UNSUPPORTED;
             }
             L.uxmax = u.xmax;
             if ((s = upload_vec(e, pl, u.xofs, &L.d_uxofs)) || (s = upload_vec(e, pl, u.yofs, &L.d_uyofs)) ||
-                (s = upload_vec(e, pl, u.alpha, &L.d_ualpha)) || (s = upload_vec(e, pl, u.beta, &L.d_ubeta)))
+                (s = upload_vec(e, pl, u.alpha, &L.d_ualpha)) || (s = upload_vec(e, pl, u.beta, &L.d_ubeta))) {
+                free_plan(pl);
                 return s;
+            }
         }
     }
     e->plans[key] = pl;
@@ -402,48 +438,63 @@ tw_status get_plan(tw_engine* e, int w0, int h0, Plan** out)
     return TW_OK;
 }
 
-tw_status slot_reserve(tw_engine* e, Slot& s, const Plan* pl, int span, bool need_img)
+// Device workspace for a plan (grown, never shrunk).  Safe to reallocate only when nothing is queued.
+tw_status reserve_workspace(tw_engine* e, const Plan* pl, int span, bool need_img)
 {
-    const LevelPlan& L0 = pl->lv[0];
-    size_t px = (size_t)L0.ps;
-    for (const LevelPlan& L : pl->lv) px = std::max(px, (size_t)L.ps);
-    if (px > s.cap_px) {
-        for (int i = 0; i < 2; i++) {
-            if (s.I[i]) (void)hipFree(s.I[i]);
-            if (s.R[i]) (void)hipFree(s.R[i]);
-            if (s.M[i]) (void)hipFree(s.M[i]);
-            if (s.flow[i]) (void)hipFree(s.flow[i]);
-            s.I[i] = s.R[i] = s.M[i] = s.flow[i] = nullptr;
+    size_t need = 0;
+    for (const LevelPlan& L : pl->lv) need = std::max(need, (size_t)L.ps * 2 * L.chunk);
+    bool grow = need > e->ws_elems || e->flow.size() < pl->lv.size();
+    if (!grow)
+        for (size_t k = 0; k < pl->lv.size(); k++) {
+            const size_t fc = (size_t)pl->lv[k].ps * 2 * (k == 0 ? pl->lv[0].chunk : e->cap);
+            if (fc > e->flow_cap[k]) grow = true;
         }
-        s.cap_px = 0;
-        for (int i = 0; i < 2; i++) {
-            TW_HIP(e, hipMalloc((void**)&s.I[i], px * 4 + 256));
-            TW_HIP(e, hipMalloc((void**)&s.R[i], px * 5 * 4 + 256));
-            TW_HIP(e, hipMalloc((void**)&s.M[i], px * 5 * 4 + 256));
-            TW_HIP(e, hipMalloc((void**)&s.flow[i], px * 2 * 4 + 256));
-        }
-        s.cap_px = px;
+    const size_t img = (size_t)pl->w0 * pl->h0 * 2 * e->cap;
+    const size_t G = span > 0 ? (size_t)tw_grid_capacity(pl->w0, pl->h0, span) : 0;
+    if (need_img && img > e->d_img_cap) grow = true;
+    if (G * e->cap > e->d_rec_cap) grow = true;
+    if (!grow) return TW_OK;
+    TW_HIP(e, hipStreamSynchronize(e->stream));
+    if (need > e->ws_elems) {
+        if (e->I) (void)hipFree(e->I);
+        if (e->R) (void)hipFree(e->R);
+        if (e->M[0]) (void)hipFree(e->M[0]);
+        if (e->M[1]) (void)hipFree(e->M[1]);
+        e->I = e->R = e->M[0] = e->M[1] = nullptr;
+        e->ws_elems = 0;
+        TW_HIP(e, hipMalloc((void**)&e->I, need * 4 + 256));
+        TW_HIP(e, hipMalloc((void**)&e->R, need * 5 * 4 + 256));
+        TW_HIP(e, hipMalloc((void**)&e->M[0], need / 2 * 5 * 4 + 256));
+        TW_HIP(e, hipMalloc((void**)&e->M[1], need / 2 * 5 * 4 + 256));
+        e->ws_elems = need;
     }
-    const size_t img = (size_t)pl->w0 * pl->h0 * 2;
-    if (need_img && img > s.img_cap) {
-        if (s.d_img) (void)hipFree(s.d_img);
-        if (s.h_img) (void)hipHostFree(s.h_img);
-        s.d_img = nullptr;
-        s.h_img = nullptr;
-        s.img_cap = 0;
-        TW_HIP(e, hipMalloc((void**)&s.d_img, img + 256));
-        TW_HIP(e, hipHostMalloc((void**)&s.h_img, img, hipHostMallocDefault));
-        s.img_cap = img;
+    if (e->flow.size() < pl->lv.size()) {
+        e->flow.resize(pl->lv.size(), nullptr);
+        e->flow_cap.resize(pl->lv.size(), 0);
     }
-    if (span > 0) {
-        const size_t G = (size_t)tw_grid_capacity(pl->w0, pl->h0, span);
-        if (G > s.rec_cap) {
-            if (s.d_rec) (void)hipFree(s.d_rec);
-            s.d_rec = nullptr;
-            s.rec_cap = 0;
-            TW_HIP(e, hipMalloc((void**)&s.d_rec, G * sizeof(ScanRec) + 256));
-            s.rec_cap = G;
+    for (size_t k = 0; k < pl->lv.size(); k++) {
+        const size_t fc = (size_t)pl->lv[k].ps * 2 * (k == 0 ? pl->lv[0].chunk : e->cap);
+        if (fc > e->flow_cap[k]) {
+            if (e->flow[k]) (void)hipFree(e->flow[k]);
+            e->flow[k] = nullptr;
+            e->flow_cap[k] = 0;
+            TW_HIP(e, hipMalloc((void**)&e->flow[k], fc * 4 + 256));
+            e->flow_cap[k] = fc;
         }
+    }
+    if (need_img && img > e->d_img_cap) {
+        if (e->d_img) (void)hipFree(e->d_img);
+        e->d_img = nullptr;
+        e->d_img_cap = 0;
+        TW_HIP(e, hipMalloc((void**)&e->d_img, img + 256));
+        e->d_img_cap = img;
+    }
+    if (G * e->cap > e->d_rec_cap) {
+        if (e->d_rec) (void)hipFree(e->d_rec);
+        e->d_rec = nullptr;
+        e->d_rec_cap = 0;
+        TW_HIP(e, hipMalloc((void**)&e->d_rec, G * e->cap * sizeof(ScanRec) + 256));
+        e->d_rec_cap = G * e->cap;
     }
     return TW_OK;
 }
@@ -485,16 +536,15 @@ struct ProfScope {
     }
 };
 
-// ---- kernel launch helpers -------------------------------------------------------------------------
-void launch_pyr(tw_engine* e, hipStream_t st, const Plan* pl, int k, const uint8_t* img0, const uint8_t* img1,
-                long long stride, float* I0, float* I1, int nimg)
+// ---- kernel launch helpers (nz = images or pairs in this launch) -------------------------------------
+void launch_pyr(tw_engine* e, hipStream_t st, const Plan* pl, int k, const uint8_t* const* d_srcs, long long stride,
+                float* I, int nimg)
 {
     const LevelPlan& L = pl->lv[k];
     PyrArgs a;
-    a.src[0] = img0;
-    a.src[1] = img1;
-    a.dst[0] = I0;
-    a.dst[1] = I1;
+    a.srcs = d_srcs;
+    a.dst = I;
+    a.dst_zs = L.ps;
     a.stride = stride;
     a.w0 = pl->w0;
     a.h0 = pl->h0;
@@ -517,14 +567,12 @@ void launch_pyr(tw_engine* e, hipStream_t st, const Plan* pl, int k, const uint8
     hipLaunchKernelGGL(tw_pyr_level, grid, dim3(256), lds, st, a);
 }
 
-tw_status launch_polyexp(tw_engine* e, hipStream_t st, int w, int h, int ld, long long ps, const float* I0,
-                         const float* I1, float* R0, float* R1, int nimg, int level)
+tw_status launch_polyexp(tw_engine* e, hipStream_t st, int w, int h, int ld, long long ps, const float* I, float* R,
+                         int nimg, int level)
 {
     PolyArgs a;
-    a.src[0] = I0;
-    a.src[1] = I1;
-    a.dst[0] = R0;
-    a.dst[1] = R1;
+    a.src = I;
+    a.dst = R;
     a.w = w;
     a.h = h;
     a.ld = ld;
@@ -545,15 +593,32 @@ tw_status launch_polyexp(tw_engine* e, hipStream_t st, int w, int h, int ld, lon
     return TW_OK;
 }
 
+void launch_refresh(tw_engine* e, hipStream_t st, int w, int h, int ld, long long ps, const float* R, float* flow,
+                    float* M, int level, int npairs)
+{
+    UpdArgs a;
+    memset(&a, 0, sizeof(a));
+    a.R = R;
+    a.flow = flow;
+    a.M = M;
+    a.w = w;
+    a.h = h;
+    a.ld = ld;
+    a.ps = ps;
+    a.fps = ps;
+    dim3 grid((w + 63) / 64, (h + 3) / 4, npairs);
+    ProfScope pscope(e, st, TW_K_UPDATE_MATRICES, level);
+    hipLaunchKernelGGL(tw_update_matrices<false>, grid, dim3(256), 0, st, a);
+}
+
 void launch_blur(tw_engine* e, hipStream_t st, int w, int h, int ld, long long ps, const float* Min, float* Mout,
-                 float* flow, const float* R0, const float* R1, int update, int level)
+                 float* flow, const float* R, int update, int level, int npairs)
 {
     BlurArgs a;
     a.Min = Min;
     a.Mout = Mout;
     a.flow = flow;
-    a.R0 = R0;
-    a.R1 = R1;
+    a.R = R;
     a.w = w;
     a.h = h;
     a.ld = ld;
@@ -563,37 +628,54 @@ void launch_blur(tw_engine* e, hipStream_t st, int w, int h, int ld, long long p
     a.m = e->win_m;
     a.c = e->wc;
     const int gy = (h + BS_TH - 1) / BS_TH;
-    ProfScope pscope(e, st, TW_K_BLUR_SOLVE, level);
-    if (e->win_m == 15) {
-        if (w > 480) {
-            constexpr int TW = 256 - 32;
-            hipLaunchKernelGGL((tw_blur_solve<15, 256, 16>), dim3((w + TW - 1) / TW, gy), dim3(256), 0, st, a);
+    const bool wide = w > 480;
+    bool fused = true;
+    {
+        ProfScope pscope(e, st, TW_K_BLUR_SOLVE, level);
+        if (e->win_m == 15 && (e->blur_variant == 4 || e->blur_variant == 5)) {
+            // v3 structure: 4 = separate refresh kernel, 5 = refresh fused into the solve phase
+            if (e->blur_variant == 4) {
+                fused = false;
+                if (wide) hipLaunchKernelGGL((tw_blur_solve3<15, 256, 16, 8, false>), dim3((w + 223) / 224, gy, npairs), dim3(256), 0, st, a);
+                else hipLaunchKernelGGL((tw_blur_solve3<15, 128, 16, 8, false>), dim3((w + 95) / 96, gy, npairs), dim3(128), 0, st, a);
+            } else {
+                if (wide) hipLaunchKernelGGL((tw_blur_solve3<15, 256, 16, 8, true>), dim3((w + 223) / 224, gy, npairs), dim3(256), 0, st, a);
+                else hipLaunchKernelGGL((tw_blur_solve3<15, 128, 16, 8, true>), dim3((w + 95) / 96, gy, npairs), dim3(128), 0, st, a);
+            }
+        } else if (e->win_m == 15 && e->blur_variant >= 1) {
+            fused = false;
+            if (e->blur_variant == 2) {
+                const int gy9 = (h + 8) / 9;
+                if (wide) hipLaunchKernelGGL((tw_blur_solve2<15, 256, 16, 9, 3>), dim3((w + 223) / 224, gy9, npairs), dim3(256), 0, st, a);
+                else hipLaunchKernelGGL((tw_blur_solve2<15, 128, 16, 9, 3>), dim3((w + 95) / 96, gy9, npairs), dim3(128), 0, st, a);
+            } else if (e->blur_variant == 3) {
+                if (wide) hipLaunchKernelGGL((tw_blur_solve2<15, 256, 16, 8, 4>), dim3((w + 223) / 224, gy, npairs), dim3(256), 0, st, a);
+                else hipLaunchKernelGGL((tw_blur_solve2<15, 128, 16, 8, 4>), dim3((w + 95) / 96, gy, npairs), dim3(128), 0, st, a);
+            } else {
+                if (wide) hipLaunchKernelGGL((tw_blur_solve2<15, 256, 16, 8, 2>), dim3((w + 223) / 224, gy, npairs), dim3(256), 0, st, a);
+                else hipLaunchKernelGGL((tw_blur_solve2<15, 128, 16, 8, 2>), dim3((w + 95) / 96, gy, npairs), dim3(128), 0, st, a);
+            }
+        } else if (e->win_m == 15) {
+            if (wide) hipLaunchKernelGGL((tw_blur_solve<15, 256, 16>), dim3((w + 223) / 224, gy, npairs), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((tw_blur_solve<15, 128, 16>), dim3((w + 95) / 96, gy, npairs), dim3(128), 0, st, a);
+        } else if (e->win_m == 25) {
+            if (wide) hipLaunchKernelGGL((tw_blur_solve<25, 256, 32>), dim3((w + 191) / 192, gy, npairs), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((tw_blur_solve<25, 128, 32>), dim3((w + 63) / 64, gy, npairs), dim3(128), 0, st, a);
         } else {
-            constexpr int TW = 128 - 32;
-            hipLaunchKernelGGL((tw_blur_solve<15, 128, 16>), dim3((w + TW - 1) / TW, gy), dim3(128), 0, st, a);
+            const size_t lds = (size_t)5 * BS_TH * (64 + 2 * e->win_m) * 4;
+            hipLaunchKernelGGL(tw_blur_solve_generic, dim3((w + 63) / 64, gy, npairs), dim3(256), lds, st, a);
         }
-    } else if (e->win_m == 25) {
-        if (w > 480) {
-            constexpr int TW = 256 - 64;
-            hipLaunchKernelGGL((tw_blur_solve<25, 256, 32>), dim3((w + TW - 1) / TW, gy), dim3(256), 0, st, a);
-        } else {
-            constexpr int TW = 128 - 64;
-            hipLaunchKernelGGL((tw_blur_solve<25, 128, 32>), dim3((w + TW - 1) / TW, gy), dim3(128), 0, st, a);
-        }
-    } else {
-        const size_t lds = (size_t)5 * BS_TH * (64 + 2 * e->win_m) * 4;
-        hipLaunchKernelGGL(tw_blur_solve_generic, dim3((w + 63) / 64, gy), dim3(256), lds, st, a);
     }
+    if (!fused && update) launch_refresh(e, st, w, h, ld, ps, R, flow, Mout, level, npairs);
 }
 
-void launch_update(tw_engine* e, hipStream_t st, const Plan* pl, int k, const float* R0, const float* R1,
-                   float* flow, const float* prev, float* M)
+void launch_update(tw_engine* e, hipStream_t st, const Plan* pl, int k, const float* R, float* flow,
+                   const float* prev, float* M, int npairs)
 {
     const LevelPlan& L = pl->lv[k];
     UpdArgs a;
     memset(&a, 0, sizeof(a));
-    a.R0 = R0;
-    a.R1 = R1;
+    a.R = R;
     a.flow = flow;
     a.M = M;
     a.w = L.w;
@@ -601,7 +683,7 @@ void launch_update(tw_engine* e, hipStream_t st, const Plan* pl, int k, const fl
     a.ld = L.ld;
     a.ps = L.ps;
     a.fps = L.ps;
-    dim3 grid((L.w + 63) / 64, (L.h + 3) / 4);
+    dim3 grid((L.w + 63) / 64, (L.h + 3) / 4, npairs);
     ProfScope pscope(e, st, TW_K_UPDATE_MATRICES, k);
     if (k < pl->levels) {
         const LevelPlan& P = pl->lv[k + 1];
@@ -623,51 +705,81 @@ void launch_update(tw_engine* e, hipStream_t st, const Plan* pl, int k, const fl
     }
 }
 
-// Enqueue the whole pair on the slot's stream.  Returns the index of the flow buffer holding level 0.
-tw_status enqueue_pair(tw_engine* e, Slot& s, const Plan* pl, const uint8_t* d_a, const uint8_t* d_b,
-                       long long stride, int span, double threshold)
+// Enqueue a whole batch, level-major: every level is processed for all pairs (in chunks sized to fill the
+// chip) before the next finer level starts; level 0 chunks are scanned as soon as their flow exists.
+tw_status flush_ctx(tw_engine* e, Ctx& c)
 {
-    hipStream_t st = s.stream;
-    TW_HIP(e, hipEventRecord(s.ev_start, st));
+    if (c.launched || c.jobs.empty()) return TW_OK;
+    hipStream_t st = e->stream;
+    Plan* pl = nullptr;
+    tw_status r = get_plan(e, c.w, c.h, &pl);
+    if (r) return r;
+    if ((r = reserve_workspace(e, pl, c.span, c.any_host))) return r;
+    const int n = (int)c.jobs.size();
+    const size_t npx = (size_t)c.w * c.h;
+    long long stride = c.jobs[0].stride;
+    if (c.any_host) {
+        TW_HIP(e, hipMemcpyAsync(e->d_img, c.h_img, npx * 2 * n, hipMemcpyHostToDevice, st));
+        stride = c.w;
+    }
+    for (int j = 0; j < n; j++) {
+        const Job& jb = c.jobs[j];
+        if (jb.h_a) {
+            c.h_ptrs[2 * j] = e->d_img + npx * (2 * j);
+            c.h_ptrs[2 * j + 1] = e->d_img + npx * (2 * j + 1);
+        } else {
+            c.h_ptrs[2 * j] = jb.d_a;
+            c.h_ptrs[2 * j + 1] = jb.d_b;
+        }
+    }
+    TW_HIP(e, hipMemcpyAsync((void*)e->d_ptrs, c.h_ptrs, sizeof(void*) * 2 * n, hipMemcpyHostToDevice, st));
+    TW_HIP(e, hipEventRecord(c.ev_start, st));
+    const int it = e->p.pyrIterations;
     for (int k = pl->levels; k >= 0; k--) {
         const LevelPlan& L = pl->lv[k];
-        float* flow_cur = s.flow[k & 1];
-        const float* flow_prev = s.flow[(k + 1) & 1];
-        launch_pyr(e, st, pl, k, d_a, d_b, stride, s.I[0], s.I[1], 2);
-        tw_status r = launch_polyexp(e, st, L.w, L.h, L.ld, L.ps, s.I[0], s.I[1], s.R[0], s.R[1], 2, k);
-        if (r) return r;
-        launch_update(e, st, pl, k, s.R[0], s.R[1], flow_cur, flow_prev, s.M[0]);
-        for (int i = 0; i < e->p.pyrIterations; i++)
-            launch_blur(e, st, L.w, L.h, L.ld, L.ps, s.M[i & 1], s.M[(i + 1) & 1], flow_cur, s.R[0], s.R[1],
-                        i < e->p.pyrIterations - 1, k);
-    }
-    s.final_flow = 0;
-    TW_HIP(e, hipEventRecord(s.ev_stop, st));
-    if (span > 0) {
-        const LevelPlan& L0 = pl->lv[0];
-        ScanArgs a;
-        a.flow = s.flow[0];
-        a.fps = L0.ps;
-        a.w = L0.w;
-        a.h = L0.h;
-        a.ld = L0.ld;
-        a.span = span;
-        a.gw = (L0.w + span - 1) / span;
-        a.gh = (L0.h + span - 1) / span;
-        a.thr2 = threshold * threshold;
-        a.count = s.d_count;
-        a.rec = s.d_rec;
-        {
-            ProfScope pscope(e, st, TW_K_SCAN, 0);
-            hipLaunchKernelGGL(tw_span_scan, dim3(1), dim3(1024), 0, st, a);
+        for (int j0 = 0; j0 < n; j0 += L.chunk) {
+            const int nc = std::min(L.chunk, n - j0);
+            // flow buffers: levels >= 1 keep every pair of the batch, level 0 only the current chunk
+            float* flow_cur = e->flow[k] + (k == 0 ? 0 : (size_t)j0 * 2 * L.ps);
+            const float* flow_prev =
+                k < pl->levels ? e->flow[k + 1] + (size_t)j0 * 2 * pl->lv[k + 1].ps : nullptr;
+            launch_pyr(e, st, pl, k, e->d_ptrs + 2 * j0, stride, e->I, 2 * nc);
+            if ((r = launch_polyexp(e, st, L.w, L.h, L.ld, L.ps, e->I, e->R, 2 * nc, k))) return r;
+            launch_update(e, st, pl, k, e->R, flow_cur, flow_prev, e->M[0], nc);
+            for (int i = 0; i < it; i++)
+                launch_blur(e, st, L.w, L.h, L.ld, L.ps, e->M[i & 1], e->M[(i + 1) & 1], flow_cur, e->R, i < it - 1,
+                            k, nc);
+            if (k == 0 && c.span > 0) {
+                ScanArgs a;
+                a.flow = flow_cur;
+                a.fzs = 2 * L.ps;
+                a.fps = L.ps;
+                a.w = L.w;
+                a.h = L.h;
+                a.ld = L.ld;
+                a.span = c.span;
+                a.gw = (L.w + c.span - 1) / c.span;
+                a.gh = (L.h + c.span - 1) / c.span;
+                a.thr2 = c.threshold * c.threshold;
+                a.count = e->d_count + j0;
+                a.rec_zs = (long long)a.gw * a.gh;
+                a.rec = e->d_rec + (size_t)j0 * a.rec_zs;
+                ProfScope pscope(e, st, TW_K_SCAN, 0);
+                hipLaunchKernelGGL(tw_span_scan, dim3(nc), dim3(1024), 0, st, a);
+            }
         }
-        // count + the first HOST_RECS records; the rest (rare) is fetched in tw_wait
-        TW_HIP(e, hipMemcpyAsync(s.h_count, s.d_count, sizeof(int), hipMemcpyDeviceToHost, st));
-        const size_t n = std::min((size_t)HOST_RECS, s.rec_cap);
-        TW_HIP(e, hipMemcpyAsync(s.h_count + 4, s.d_rec, n * sizeof(ScanRec), hipMemcpyDeviceToHost, st));
+    }
+    TW_HIP(e, hipEventRecord(c.ev_stop, st));
+    if (c.span > 0) {
+        const size_t G = (size_t)tw_grid_capacity(c.w, c.h, c.span);
+        const size_t nrec = std::min((size_t)HOST_RECS, G);
+        TW_HIP(e, hipMemcpyAsync(c.h_count, e->d_count, sizeof(int) * n, hipMemcpyDeviceToHost, st));
+        TW_HIP(e, hipMemcpy2DAsync(c.h_rec, HOST_RECS * sizeof(ScanRec), e->d_rec, G * sizeof(ScanRec),
+                                   nrec * sizeof(ScanRec), n, hipMemcpyDeviceToHost, st));
     }
     TW_HIP(e, hipGetLastError());
-    TW_HIP(e, hipEventRecord(s.ev_done, st));
+    TW_HIP(e, hipEventRecord(c.ev_done, st));
+    c.launched = true;
     return TW_OK;
 }
 
@@ -692,45 +804,76 @@ tw_status submit_common(tw_engine* e, const uint8_t* h_a, const uint8_t* h_b, co
         return TW_E_BAD_PARAMETER;
     }
     TW_HIP(e, hipSetDevice(e->device));
-    int si = -1;
-    for (int i = 0; i < e->nslots; i++) {
-        const int c = (e->next_slot + i) % e->nslots;
-        if (!e->slots[c].busy) {
-            si = c;
-            break;
+    // host images are staged densely; device images are read in place with their own row stride
+    const long long eff_stride = h_a ? (long long)width : (long long)stride;
+    Ctx* c = &e->ctx[e->cur];
+    // a batch is homogeneous: same size, span, threshold and row stride
+    const bool open = !c->launched && !c->jobs.empty();
+    const bool fits = open && c->w == width && c->h == height && c->span == span && c->threshold == threshold &&
+                      c->jobs[0].stride == eff_stride && (int)c->jobs.size() < e->cap;
+    if (!fits) {
+        if (open && (r = flush_ctx(e, *c))) return r;
+        if (c->pending > 0) {  // still owed to the caller: move on to the next context
+            const int nxt = (e->cur + 1) % NCTX;
+            if (e->ctx[nxt].pending > 0) return TW_E_BUSY;
+            e->cur = nxt;
+            c = &e->ctx[nxt];
         }
+        c->jobs.clear();
+        c->launched = false;
+        c->pending = 0;
+        c->w = width;
+        c->h = height;
+        c->span = span;
+        c->threshold = threshold;
+        c->any_host = false;
+        c->first_ticket = e->next_ticket;
     }
-    if (si < 0) return TW_E_BUSY;
-    e->next_slot = (si + 1) % e->nslots;
-    Slot& s = e->slots[si];
-    Plan* pl = nullptr;
-    if ((r = get_plan(e, width, height, &pl))) return r;
-    if ((r = slot_reserve(e, s, pl, span, h_a != nullptr))) return r;
-    const uint8_t *da, *db;
-    long long dstride;
+    Job jb;
+    jb.stride = eff_stride;
     if (h_a) {
-        const size_t n = (size_t)width * height;
-        for (int y = 0; y < height; y++) {
-            memcpy(s.h_img + (size_t)y * width, h_a + (size_t)y * stride, width);
-            memcpy(s.h_img + n + (size_t)y * width, h_b + (size_t)y * stride, width);
+        const size_t npx = (size_t)width * height;
+        const size_t need = npx * 2 * e->cap;
+        if (need > c->h_img_cap) {
+            // only ever happens on the first job of a batch (all jobs of a batch have one size)
+            if (c->h_img) (void)hipHostFree(c->h_img);
+            c->h_img = nullptr;
+            c->h_img_cap = 0;
+            TW_HIP(e, hipHostMalloc((void**)&c->h_img, need, hipHostMallocDefault));
+            c->h_img_cap = need;
         }
-        TW_HIP(e, hipMemcpyAsync(s.d_img, s.h_img, 2 * n, hipMemcpyHostToDevice, s.stream));
-        da = s.d_img;
-        db = s.d_img + n;
-        dstride = width;
+        const size_t j = c->jobs.size();
+        uint8_t* da = c->h_img + npx * (2 * j);
+        uint8_t* db = c->h_img + npx * (2 * j + 1);
+        for (int y = 0; y < height; y++) {
+            memcpy(da + (size_t)y * width, h_a + (size_t)y * stride, width);
+            memcpy(db + (size_t)y * width, h_b + (size_t)y * stride, width);
+        }
+        jb.h_a = da;
+        jb.h_b = db;
+        c->any_host = true;
     } else {
-        da = (const uint8_t*)d_a;
-        db = (const uint8_t*)d_b;
-        dstride = stride;
+        jb.d_a = (const uint8_t*)d_a;
+        jb.d_b = (const uint8_t*)d_b;
     }
-    s.w = width;
-    s.h = height;
-    s.span = span;
-    if ((r = enqueue_pair(e, s, pl, da, db, dstride, span, threshold))) return r;
-    s.busy = true;
-    s.gen++;
-    if (ticket) *ticket = (tw_ticket)(s.gen * 1024 + si);
+    c->jobs.push_back(jb);
+    c->pending++;
+    if (ticket) *ticket = e->next_ticket;
+    e->next_ticket++;
+    if ((int)c->jobs.size() == e->cap) return flush_ctx(e, *c);
     return TW_OK;
+}
+
+Ctx* find_ctx(tw_engine* e, tw_ticket t, int* idx)
+{
+    for (Ctx& c : e->ctx) {
+        const int64_t j = t - c.first_ticket;
+        if (c.pending > 0 && j >= 0 && j < (int64_t)c.jobs.size() && !c.jobs[j].waited) {
+            *idx = (int)j;
+            return &c;
+        }
+    }
+    return nullptr;
 }
 
 }  // namespace
@@ -795,27 +938,32 @@ tw_status tw_engine_create(int device, const tw_params* params, int slots, tw_en
     if (!(p.flags & 256)) return TW_E_UNSUPPORTED;  // box window: not built yet
     if (p.pyrIterations < 0 || p.pyrLevels < 0) return TW_E_BAD_PARAMETER;
     if (slots < 1) slots = 1;
-    if (slots > 64) slots = 64;
+    if (slots > 256) slots = 256;
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return TW_E_DEVICE;
     if (hipSetDevice(device) != hipSuccess) return TW_E_DEVICE;
     tw_engine* e = new tw_engine();
     e->device = device;
     e->p = p;
-    e->nslots = slots;
-    e->slots.resize(slots);
+    e->cap = slots;
     polyexp_setup(p.polyN, p.polySigma, e->pc);
     window_kernel(p.winSize, e->wc);
     e->win_m = p.winSize / 2;
-    for (Slot& s : e->slots) {
-        if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreate(&s.ev_start) != hipSuccess || hipEventCreate(&s.ev_stop) != hipSuccess ||
-            hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming) != hipSuccess ||
-            hipMalloc((void**)&s.d_count, 256) != hipSuccess ||
-            hipHostMalloc((void**)&s.h_count, 16 + HOST_RECS * sizeof(ScanRec), hipHostMallocDefault) != hipSuccess) {
-            tw_engine_destroy(e);
-            return TW_E_DEVICE;
-        }
+    if (const char* ev = getenv("TW_BLUR_VARIANT")) e->blur_variant = atoi(ev);
+    bool ok = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) == hipSuccess &&
+              hipMalloc((void**)&e->d_ptrs, sizeof(void*) * 2 * slots + 256) == hipSuccess &&
+              hipMalloc((void**)&e->d_count, sizeof(int) * slots + 256) == hipSuccess;
+    for (Ctx& c : e->ctx) {
+        ok = ok && hipEventCreate(&c.ev_start) == hipSuccess && hipEventCreate(&c.ev_stop) == hipSuccess &&
+             hipEventCreateWithFlags(&c.ev_done, hipEventDisableTiming) == hipSuccess &&
+             hipHostMalloc((void**)&c.h_ptrs, sizeof(void*) * 2 * slots, hipHostMallocDefault) == hipSuccess &&
+             hipHostMalloc((void**)&c.h_count, sizeof(int) * slots, hipHostMallocDefault) == hipSuccess &&
+             hipHostMalloc((void**)&c.h_rec, sizeof(ScanRec) * HOST_RECS * (size_t)slots, hipHostMallocDefault) ==
+                 hipSuccess;
+    }
+    if (!ok) {
+        tw_engine_destroy(e);
+        return TW_E_DEVICE;
     }
     *out = e;
     return TW_OK;
@@ -826,27 +974,27 @@ void tw_engine_destroy(tw_engine* e)
     if (!e) return;
     (void)hipSetDevice(e->device);
     (void)hipDeviceSynchronize();
-    for (Slot& s : e->slots) {
-        for (int i = 0; i < 2; i++) {
-            if (s.I[i]) (void)hipFree(s.I[i]);
-            if (s.R[i]) (void)hipFree(s.R[i]);
-            if (s.M[i]) (void)hipFree(s.M[i]);
-            if (s.flow[i]) (void)hipFree(s.flow[i]);
-        }
-        if (s.d_img) (void)hipFree(s.d_img);
-        if (s.h_img) (void)hipHostFree(s.h_img);
-        if (s.d_count) (void)hipFree(s.d_count);
-        if (s.d_rec) (void)hipFree(s.d_rec);
-        if (s.h_count) (void)hipHostFree(s.h_count);
-        if (s.ev_start) (void)hipEventDestroy(s.ev_start);
-        if (s.ev_stop) (void)hipEventDestroy(s.ev_stop);
-        if (s.ev_done) (void)hipEventDestroy(s.ev_done);
-        if (s.stream) (void)hipStreamDestroy(s.stream);
+    if (e->I) (void)hipFree(e->I);
+    if (e->R) (void)hipFree(e->R);
+    if (e->M[0]) (void)hipFree(e->M[0]);
+    if (e->M[1]) (void)hipFree(e->M[1]);
+    for (float* f : e->flow)
+        if (f) (void)hipFree(f);
+    if (e->d_img) (void)hipFree(e->d_img);
+    if (e->d_ptrs) (void)hipFree((void*)e->d_ptrs);
+    if (e->d_count) (void)hipFree(e->d_count);
+    if (e->d_rec) (void)hipFree(e->d_rec);
+    for (Ctx& c : e->ctx) {
+        if (c.h_img) (void)hipHostFree(c.h_img);
+        if (c.h_ptrs) (void)hipHostFree((void*)c.h_ptrs);
+        if (c.h_count) (void)hipHostFree(c.h_count);
+        if (c.h_rec) (void)hipHostFree(c.h_rec);
+        if (c.ev_start) (void)hipEventDestroy(c.ev_start);
+        if (c.ev_stop) (void)hipEventDestroy(c.ev_stop);
+        if (c.ev_done) (void)hipEventDestroy(c.ev_done);
     }
-    for (auto& kv : e->plans) {
-        for (void* d : kv.second->owned) (void)hipFree(d);
-        delete kv.second;
-    }
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    for (auto& kv : e->plans) free_plan(kv.second);
     for (auto& pend : e->prof_pending)
         for (ProfPair& pp : pend) {
             (void)hipEventDestroy(pp.a);
@@ -870,37 +1018,56 @@ tw_status tw_submit_dev(tw_engine* e, const void* d_expect, const void* d_target
     return submit_common(e, nullptr, nullptr, d_expect, d_target, width, height, stride, span, threshold, ticket);
 }
 
+tw_status tw_flush(tw_engine* e)
+{
+    if (!e) return TW_E_BAD_PARAMETER;
+    TW_HIP(e, hipSetDevice(e->device));
+    return flush_ctx(e, e->ctx[e->cur]);
+}
+
 tw_status tw_wait(tw_engine* e, tw_ticket ticket, tw_vector* out, int cap, int* n, float* seconds)
 {
     if (!e) return TW_E_BAD_PARAMETER;
-    const int si = (int)(ticket % 1024);
-    const int64_t gen = ticket / 1024;
-    if (si < 0 || si >= e->nslots || !e->slots[si].busy || e->slots[si].gen != gen) {
+    int j = 0;
+    Ctx* c = find_ctx(e, ticket, &j);
+    if (!c) {
         e->err = "unknown ticket";
         return TW_E_BAD_PARAMETER;
     }
-    Slot& s = e->slots[si];
     TW_HIP(e, hipSetDevice(e->device));
-    hipError_t herr = hipEventSynchronize(s.ev_done);
-    s.busy = false;
+    tw_status r;
+    if (!c->launched && (r = flush_ctx(e, *c))) {
+        // the batch cannot run: drop it so that the engine stays usable
+        c->pending = 0;
+        c->jobs.clear();
+        return r;
+    }
+    hipError_t herr = hipEventSynchronize(c->ev_done);
+    c->jobs[j].waited = true;
+    c->pending--;
     if (herr != hipSuccess) {
         e->err = std::string("hipEventSynchronize: ") + hipGetErrorString(herr);
         return TW_E_DEVICE;
     }
     if (seconds) {
+        // device compute time of the batch, shared equally by its pairs (exact for a batch of one)
         float ms = 0.f;
-        TW_HIP(e, hipEventElapsedTime(&ms, s.ev_start, s.ev_stop));
-        *seconds = ms * 1e-3f;
+        TW_HIP(e, hipEventElapsedTime(&ms, c->ev_start, c->ev_stop));
+        *seconds = ms * 1e-3f / (float)c->jobs.size();
     }
-    if (s.span > 0) {
-        const int cnt = s.h_count[0];
+    if (c->span > 0) {
+        const int cnt = c->h_count[j];
         if (n) *n = cnt;
         const int want = std::min(cnt, cap);
-        const ScanRec* hr = (const ScanRec*)(s.h_count + 4);
+        const ScanRec* hr = c->h_rec + (size_t)j * HOST_RECS;
         std::vector<ScanRec> extra;
-        if (want > HOST_RECS) {
+        if (want > HOST_RECS && out) {
+            // rare: more hits than the eager copy holds.  The device records are intact as long as no
+            // later batch of this engine has been flushed.
+            const size_t G = (size_t)tw_grid_capacity(c->w, c->h, c->span);
             extra.resize(want);
-            TW_HIP(e, hipMemcpy(extra.data(), s.d_rec, (size_t)want * sizeof(ScanRec), hipMemcpyDeviceToHost));
+            TW_HIP(e, hipMemcpy(extra.data(), e->d_rec + (size_t)j * G, (size_t)want * sizeof(ScanRec),
+                                hipMemcpyDeviceToHost));
             hr = extra.data();
         }
         if (out)
@@ -929,17 +1096,19 @@ tw_status tw_diff_u8(tw_engine* e, const uint8_t* expect, const uint8_t* target,
 tw_status tw_flow_u8(tw_engine* e, const uint8_t* expect, const uint8_t* target, int width, int height,
                      ptrdiff_t stride, float* flowx, float* flowy, float* seconds)
 {
-    tw_ticket t;
-    tw_status r = tw_submit_u8(e, expect, target, width, height, stride, 0, 0.0, &t);
+    if (!e) return TW_E_BAD_PARAMETER;
+    // the dense flow of a pair lives in the level-0 chunk buffer: run this pair as a batch of its own
+    tw_status r = tw_flush(e);
     if (r) return r;
-    const int si = (int)(t % 1024);
+    tw_ticket t;
+    r = tw_submit_u8(e, expect, target, width, height, stride, 0, 0.0, &t);
+    if (r) return r;
     r = tw_wait(e, t, nullptr, 0, nullptr, seconds);
     if (r) return r;
-    Slot& s = e->slots[si];
     Plan* pl = nullptr;
     if ((r = get_plan(e, width, height, &pl))) return r;
     const LevelPlan& L0 = pl->lv[0];
-    const float* f = s.flow[s.final_flow];
+    const float* f = e->flow[0];
     if (flowx)
         TW_HIP(e, hipMemcpy2D(flowx, (size_t)width * 4, f, (size_t)L0.ld * 4, (size_t)width * 4, height,
                               hipMemcpyDeviceToHost));
@@ -1009,6 +1178,15 @@ int tw_num_levels(const tw_engine* e, int width, int height)
 {
     if (!e) return -1;
     return plan_levels(width, height, e->p.pyrScale, std::min(std::max(e->p.pyrLevels, 0), 60));
+}
+
+int tw_level_chunk(tw_engine* e, int width, int height, int level)
+{
+    if (!e) return -1;
+    if (hipSetDevice(e->device) != hipSuccess) return -1;
+    Plan* pl = nullptr;
+    if (get_plan(e, width, height, &pl) != TW_OK || level < 0 || level > pl->levels) return -1;
+    return pl->lv[level].chunk;
 }
 
 double tw_algorithmic_bytes(const tw_engine* e, int kclass, int level, int width, int height)
@@ -1092,6 +1270,113 @@ tw_status down_planes(tw_engine* e, float* h, const float* d, int ld, long long 
 }
 }  // namespace
 
+
+// ---- isolated kernel timing on synthetic device data (bench.py, tools/kbench.py) -------------------------
+extern "C" tw_status tw_bench_stage(tw_engine* e, int kclass, int width, int height, int level, int npairs,
+                                    int iters, int flags, float* avg_us)
+{
+    if (!e || !avg_us || npairs < 1 || iters < 1 || kclass < 0 || kclass >= TW_K_COUNT) return TW_E_BAD_PARAMETER;
+    TW_HIP(e, hipSetDevice(e->device));
+    Plan* pl = nullptr;
+    tw_status r = get_plan(e, width, height, &pl);
+    if (r) return r;
+    if (level < 0 || level > pl->levels) return TW_E_BAD_PARAMETER;
+    const LevelPlan& L = pl->lv[level];
+    const size_t ps = (size_t)L.ps, npx0 = (size_t)width * height;
+    const size_t pps = level < pl->levels ? (size_t)pl->lv[level + 1].ps : 1;
+    Tmp t;
+    float* I = t.alloc<float>(ps * 2 * npairs);
+    float* R = t.alloc<float>(ps * 10 * npairs);
+    float* M0 = t.alloc<float>(ps * 5 * npairs);
+    float* M1 = t.alloc<float>(ps * 5 * npairs);
+    float* fl = t.alloc<float>(ps * 2 * npairs);
+    float* pf = t.alloc<float>(pps * 2 * npairs);
+    uint8_t* img = t.alloc<uint8_t>(npx0 * 2 * npairs);
+    const uint8_t** tab = t.alloc<const uint8_t*>(2 * (size_t)npairs);
+    const int span = 10;
+    const size_t G = (size_t)tw_grid_capacity(width, height, span);
+    int* cnt = t.alloc<int>(npairs);
+    ScanRec* rec = t.alloc<ScanRec>(G * npairs);
+    if (!I || !R || !M0 || !M1 || !fl || !pf || !img || !tab || !cnt || !rec) return TW_E_NOMEM;
+    {
+        // deterministic pseudo-random fill (host LCG), smooth small flow
+        std::vector<float> hb(ps * 10);
+        uint32_t sd = 12345u;
+        auto rnd = [&]() { sd = sd * 1664525u + 1013904223u; return (float)((sd >> 8) & 0xFFFF) / 65536.f - 0.5f; };
+        for (float& v : hb) v = rnd() * 20.f;
+        // M: G = identity, h = small smooth field -> the solved flow is (h2, h1)/(1+1e-3), a few pixels
+        std::vector<float> hm(ps * 5);
+        for (size_t i = 0; i < ps; i++) {
+            hm[i] = 1.f;
+            hm[ps + i] = 0.f;
+            hm[2 * ps + i] = 1.f;
+            hm[3 * ps + i] = 2.5f * sinf((float)(i % 1931) * 0.004f);
+            hm[4 * ps + i] = 2.0f * cosf((float)(i % 2477) * 0.003f);
+        }
+        for (int j = 0; j < npairs; j++) {
+            TW_HIP(e, hipMemcpy(R + ps * 10 * j, hb.data(), ps * 10 * 4, hipMemcpyHostToDevice));
+            TW_HIP(e, hipMemcpy(M0 + ps * 5 * j, hm.data(), ps * 5 * 4, hipMemcpyHostToDevice));
+            TW_HIP(e, hipMemcpy(M1 + ps * 5 * j, hm.data(), ps * 5 * 4, hipMemcpyHostToDevice));
+            TW_HIP(e, hipMemcpy(I + ps * 2 * j, hb.data() + 17, ps * 2 * 4, hipMemcpyHostToDevice));
+        }
+        std::vector<float> hf(std::max(ps, pps) * 2);
+        for (size_t i = 0; i < hf.size(); i++) hf[i] = 3.f * sinf((float)(i % 977) * 0.01f) + (flags & 1 ? rnd() * 8.f : 0.f);
+        std::vector<uint8_t> hi(npx0);
+        for (uint8_t& v : hi) v = (uint8_t)((rnd() + 0.5f) * 255.f);
+        std::vector<const uint8_t*> ht(2 * (size_t)npairs);
+        for (int j = 0; j < npairs; j++) {
+            TW_HIP(e, hipMemcpy(fl + ps * 2 * j, hf.data(), ps * 2 * 4, hipMemcpyHostToDevice));
+            TW_HIP(e, hipMemcpy(pf + pps * 2 * j, hf.data(), pps * 2 * 4, hipMemcpyHostToDevice));
+            for (int q = 0; q < 2; q++) {
+                TW_HIP(e, hipMemcpy(img + npx0 * (2 * j + q), hi.data(), npx0, hipMemcpyHostToDevice));
+                ht[2 * j + q] = img + npx0 * (2 * j + q);
+            }
+        }
+        TW_HIP(e, hipMemcpy((void*)tab, ht.data(), sizeof(void*) * ht.size(), hipMemcpyHostToDevice));
+    }
+    hipStream_t st = e->stream;
+    hipEvent_t ea, eb;
+    TW_HIP(e, hipEventCreate(&ea));
+    TW_HIP(e, hipEventCreate(&eb));
+    int saved[TW_K_COUNT];
+    memcpy(saved, e->prof_level, sizeof(saved));
+    for (int i = 0; i < TW_K_COUNT; i++) e->prof_level[i] = -2;
+    auto once = [&](int i) -> tw_status {
+        switch (kclass) {
+            case TW_K_PYR: launch_pyr(e, st, pl, level, tab, width, I, 2 * npairs); break;
+            case TW_K_POLYEXP: return launch_polyexp(e, st, L.w, L.h, L.ld, L.ps, I, R, 2 * npairs, level);
+            case TW_K_UPDATE_MATRICES: launch_update(e, st, pl, level, R, fl, pf, M0, npairs); break;
+            case TW_K_BLUR_SOLVE:
+                launch_blur(e, st, L.w, L.h, L.ld, L.ps, (i & 1) ? M1 : M0, (i & 1) ? M0 : M1, fl, R, (flags & 2) ? 0 : 1,
+                            level, npairs);
+                break;
+            case TW_K_SCAN: {
+                ScanArgs a;
+                a.flow = fl; a.fzs = 2 * L.ps; a.fps = L.ps; a.w = L.w; a.h = L.h; a.ld = L.ld; a.span = span;
+                a.gw = (L.w + span - 1) / span; a.gh = (L.h + span - 1) / span; a.thr2 = 4.0; a.count = cnt;
+                a.rec = rec; a.rec_zs = (long long)a.gw * a.gh;
+                hipLaunchKernelGGL(tw_span_scan, dim3(npairs), dim3(1024), 0, st, a);
+            } break;
+        }
+        return TW_OK;
+    };
+    for (int i = 0; i < 2; i++)
+        if ((r = once(i))) return r;
+    TW_HIP(e, hipEventRecord(ea, st));
+    for (int i = 0; i < iters; i++)
+        if ((r = once(i))) return r;
+    TW_HIP(e, hipEventRecord(eb, st));
+    TW_HIP(e, hipGetLastError());
+    TW_HIP(e, hipEventSynchronize(eb));
+    float ms = 0;
+    TW_HIP(e, hipEventElapsedTime(&ms, ea, eb));
+    *avg_us = ms * 1e3f / iters;
+    memcpy(e->prof_level, saved, sizeof(saved));
+    (void)hipEventDestroy(ea);
+    (void)hipEventDestroy(eb);
+    return TW_OK;
+}
+
 extern "C" {
 
 tw_status tw_stage_pyr_level(tw_engine* e, const uint8_t* img, int w0, int h0, int level, float* I, int* w, int* h)
@@ -1106,10 +1391,13 @@ tw_status tw_stage_pyr_level(tw_engine* e, const uint8_t* img, int w0, int h0, i
     Tmp t;
     uint8_t* d_img = t.alloc<uint8_t>((size_t)w0 * h0);
     float* d_I = t.alloc<float>((size_t)L.ps);
-    if (!d_img || !d_I) return TW_E_NOMEM;
+    const uint8_t** d_tab = t.alloc<const uint8_t*>(1);
+    if (!d_img || !d_I || !d_tab) return TW_E_NOMEM;
     TW_HIP(e, hipMemcpy(d_img, img, (size_t)w0 * h0, hipMemcpyHostToDevice));
-    hipStream_t st = e->slots[0].stream;
-    launch_pyr(e, st, pl, level, d_img, d_img, w0, d_I, d_I, 1);
+    const uint8_t* hp = d_img;
+    TW_HIP(e, hipMemcpy((void*)d_tab, &hp, sizeof(hp), hipMemcpyHostToDevice));
+    hipStream_t st = e->stream;
+    launch_pyr(e, st, pl, level, d_tab, w0, d_I, 1);
     TW_HIP(e, hipGetLastError());
     TW_HIP(e, hipStreamSynchronize(st));
     if ((r = down_planes(e, I, d_I, L.ld, L.ps, L.w, L.h, 1))) return r;
@@ -1130,8 +1418,8 @@ tw_status tw_stage_polyexp(tw_engine* e, const float* I, int w, int h, float* R5
     if (!d_I || !d_R) return TW_E_NOMEM;
     tw_status r;
     if ((r = up_planes(e, d_I, ld, ps, I, w, h, 1))) return r;
-    hipStream_t st = e->slots[0].stream;
-    if ((r = launch_polyexp(e, st, w, h, ld, ps, d_I, d_I, d_R, d_R, 1, -1))) return r;
+    hipStream_t st = e->stream;
+    if ((r = launch_polyexp(e, st, w, h, ld, ps, d_I, d_R, 1, -1))) return r;
     TW_HIP(e, hipGetLastError());
     TW_HIP(e, hipStreamSynchronize(st));
     return down_planes(e, R5, d_R, ld, ps, w, h, 5);
@@ -1145,17 +1433,15 @@ tw_status tw_stage_update_matrices(tw_engine* e, const float* R0_5, const float*
     const int ld = round_up(w, 32);
     const long long ps = (long long)ld * h;
     Tmp t;
-    float *d_R0 = t.alloc<float>(ps * 5), *d_R1 = t.alloc<float>(ps * 5), *d_M = t.alloc<float>(ps * 5),
-          *d_f = t.alloc<float>(ps * 2);
-    if (!d_R0 || !d_R1 || !d_M || !d_f) return TW_E_NOMEM;
+    float *d_R = t.alloc<float>(ps * 10), *d_M = t.alloc<float>(ps * 5), *d_f = t.alloc<float>(ps * 2);
+    if (!d_R || !d_M || !d_f) return TW_E_NOMEM;
     tw_status r;
-    if ((r = up_planes(e, d_R0, ld, ps, R0_5, w, h, 5)) || (r = up_planes(e, d_R1, ld, ps, R1_5, w, h, 5)) ||
+    if ((r = up_planes(e, d_R, ld, ps, R0_5, w, h, 5)) || (r = up_planes(e, d_R + 5 * ps, ld, ps, R1_5, w, h, 5)) ||
         (r = up_planes(e, d_f, ld, ps, flow2, w, h, 2)))
         return r;
     UpdArgs a;
     memset(&a, 0, sizeof(a));
-    a.R0 = d_R0;
-    a.R1 = d_R1;
+    a.R = d_R;
     a.flow = d_f;
     a.M = d_M;
     a.w = w;
@@ -1163,8 +1449,8 @@ tw_status tw_stage_update_matrices(tw_engine* e, const float* R0_5, const float*
     a.ld = ld;
     a.ps = ps;
     a.fps = ps;
-    hipStream_t st = e->slots[0].stream;
-    hipLaunchKernelGGL(tw_update_matrices<false>, dim3((w + 63) / 64, (h + 3) / 4), dim3(256), 0, st, a);
+    hipStream_t st = e->stream;
+    hipLaunchKernelGGL(tw_update_matrices<false>, dim3((w + 63) / 64, (h + 3) / 4, 1), dim3(256), 0, st, a);
     TW_HIP(e, hipGetLastError());
     TW_HIP(e, hipStreamSynchronize(st));
     return down_planes(e, M5, d_M, ld, ps, w, h, 5);
@@ -1182,13 +1468,13 @@ tw_status tw_stage_flow_upsample_update(tw_engine* e, const float* R0_5, const f
     make_resize_tab(pw, ph, w, h, u);
     if (u.mode == 2) return TW_E_UNSUPPORTED;
     Tmp t;
-    float *d_R0 = t.alloc<float>(ps * 5), *d_R1 = t.alloc<float>(ps * 5), *d_M = t.alloc<float>(ps * 5),
-          *d_f = t.alloc<float>(ps * 2), *d_p = t.alloc<float>(pps * 2);
+    float *d_R = t.alloc<float>(ps * 10), *d_M = t.alloc<float>(ps * 5), *d_f = t.alloc<float>(ps * 2),
+          *d_p = t.alloc<float>(pps * 2);
     int *d_xo = t.alloc<int>(w), *d_yo = t.alloc<int>(h);
     float *d_al = t.alloc<float>(2 * (size_t)w), *d_be = t.alloc<float>(2 * (size_t)h);
-    if (!d_R0 || !d_R1 || !d_M || !d_f || !d_p || !d_xo || !d_yo || !d_al || !d_be) return TW_E_NOMEM;
+    if (!d_R || !d_M || !d_f || !d_p || !d_xo || !d_yo || !d_al || !d_be) return TW_E_NOMEM;
     tw_status r;
-    if ((r = up_planes(e, d_R0, ld, ps, R0_5, w, h, 5)) || (r = up_planes(e, d_R1, ld, ps, R1_5, w, h, 5)) ||
+    if ((r = up_planes(e, d_R, ld, ps, R0_5, w, h, 5)) || (r = up_planes(e, d_R + 5 * ps, ld, ps, R1_5, w, h, 5)) ||
         (r = up_planes(e, d_p, pld, pps, prevflow2, pw, ph, 2)))
         return r;
     TW_HIP(e, hipMemcpy(d_xo, u.xofs.data(), (size_t)w * 4, hipMemcpyHostToDevice));
@@ -1197,8 +1483,7 @@ tw_status tw_stage_flow_upsample_update(tw_engine* e, const float* R0_5, const f
     TW_HIP(e, hipMemcpy(d_be, u.beta.data(), (size_t)h * 8, hipMemcpyHostToDevice));
     UpdArgs a;
     memset(&a, 0, sizeof(a));
-    a.R0 = d_R0;
-    a.R1 = d_R1;
+    a.R = d_R;
     a.flow = d_f;
     a.M = d_M;
     a.w = w;
@@ -1217,8 +1502,8 @@ tw_status tw_stage_flow_upsample_update(tw_engine* e, const float* R0_5, const f
     a.beta = d_be;
     a.xmax = u.xmax;
     a.scale = (float)(1. / e->p.pyrScale);
-    hipStream_t st = e->slots[0].stream;
-    hipLaunchKernelGGL(tw_update_matrices<true>, dim3((w + 63) / 64, (h + 3) / 4), dim3(256), 0, st, a);
+    hipStream_t st = e->stream;
+    hipLaunchKernelGGL(tw_update_matrices<true>, dim3((w + 63) / 64, (h + 3) / 4, 1), dim3(256), 0, st, a);
     TW_HIP(e, hipGetLastError());
     TW_HIP(e, hipStreamSynchronize(st));
     if ((r = down_planes(e, flow2, d_f, ld, ps, w, h, 2))) return r;
@@ -1234,15 +1519,15 @@ tw_status tw_stage_blur_solve(tw_engine* e, const float* R0_5, const float* R1_5
     const int ld = round_up(w, 32);
     const long long ps = (long long)ld * h;
     Tmp t;
-    float *d_R0 = t.alloc<float>(ps * 5), *d_R1 = t.alloc<float>(ps * 5), *d_M = t.alloc<float>(ps * 5),
-          *d_Mo = t.alloc<float>(ps * 5), *d_f = t.alloc<float>(ps * 2);
-    if (!d_R0 || !d_R1 || !d_M || !d_Mo || !d_f) return TW_E_NOMEM;
+    float *d_R = t.alloc<float>(ps * 10), *d_M = t.alloc<float>(ps * 5), *d_Mo = t.alloc<float>(ps * 5),
+          *d_f = t.alloc<float>(ps * 2);
+    if (!d_R || !d_M || !d_Mo || !d_f) return TW_E_NOMEM;
     tw_status r;
-    if ((r = up_planes(e, d_R0, ld, ps, R0_5, w, h, 5)) || (r = up_planes(e, d_R1, ld, ps, R1_5, w, h, 5)) ||
+    if ((r = up_planes(e, d_R, ld, ps, R0_5, w, h, 5)) || (r = up_planes(e, d_R + 5 * ps, ld, ps, R1_5, w, h, 5)) ||
         (r = up_planes(e, d_M, ld, ps, M5, w, h, 5)))
         return r;
-    hipStream_t st = e->slots[0].stream;
-    launch_blur(e, st, w, h, ld, ps, d_M, d_Mo, d_f, d_R0, d_R1, update_matrices ? 1 : 0, -1);
+    hipStream_t st = e->stream;
+    launch_blur(e, st, w, h, ld, ps, d_M, d_Mo, d_f, d_R, update_matrices ? 1 : 0, -1, 1);
     TW_HIP(e, hipGetLastError());
     TW_HIP(e, hipStreamSynchronize(st));
     if ((r = down_planes(e, flow2, d_f, ld, ps, w, h, 2))) return r;

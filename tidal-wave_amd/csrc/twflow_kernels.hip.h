@@ -15,8 +15,53 @@
 namespace twk {
 
 typedef float __attribute__((ext_vector_type(4))) f32x4;
+// explicit global-address-space pointers: keeps `global_load … v_off, s[base]` (SGPR base + 32-bit VGPR
+// offset) selectable after the pointer has been made opaque to the optimiser
+typedef const float __attribute__((address_space(1))) * gptr_cf;
+typedef const char __attribute__((address_space(1))) * gptr_cc;
+
+// wave-uniform pointer pinned to an SGPR pair and hidden from loop-invariant hoisting / strength reduction
+__device__ __forceinline__ gptr_cf sgpr_base(const float* p)
+{
+    gptr_cf g = (gptr_cf)p;
+    asm volatile("" : "+s"(g));
+    return g;
+}
+__device__ __forceinline__ float gload(gptr_cf row, unsigned byte_off)
+{
+    return *(gptr_cf)((gptr_cc)row + byte_off);
+}
+
+// Raw buffer access: one resource descriptor (4 SGPRs) per image set, a wave-uniform 32-bit byte offset in
+// an SGPR (row / plane) and the lane's column as a 32-bit VGPR byte offset.  No per-load VALU address math
+// and no 64-bit pointer per row (a 2N+1-row register window otherwise costs 2 SGPRs or 2 VGPRs per row).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p)
+{
+    return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, 0xFFFFFFFFu, 0x00020000);
+}
+__device__ __forceinline__ float bload(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// XCD-aware workgroup remap.  Workgroups are dealt round-robin over the 8 XCDs (each with a private 4 MiB L2),
+// so tiles that share halo rows land on 8 different L2s and every halo row is fetched from the Infinity
+// Cache / HBM once per XCD.  Re-labelling gives every XCD one contiguous band of the (x fastest, then y, then
+// pair) tile order, so vertically adjacent tiles hit in the same L2.  Bijective for any grid size; placement
+// only affects speed, never results.
+__device__ __forceinline__ void xcd_remap(int& bx, int& by, int& bz)
+{
+    const unsigned gx = gridDim.x, gy = gridDim.y, n = gx * gy * gridDim.z;
+    unsigned b = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    const unsigned xcd = b & 7u, q = n >> 3, r = n & 7u;
+    b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+    bx = (int)(b % gx);
+    const unsigned t = b / gx;
+    by = (int)(t % gy);
+    bz = (int)(t / gy);
+}
 
 // borderInterpolate(p, len, BORDER_REFLECT_101)
 __device__ __forceinline__ int reflect101(int p, int len)
@@ -42,8 +87,9 @@ constexpr int PYR_TH = 8;
 constexpr int PYR_MAXK = 128;
 
 struct PyrArgs {
-    const uint8_t* src[2];  // two images per launch (blockIdx.z)
-    float* dst[2];
+    const uint8_t* const* srcs;  // device table of image pointers, one per blockIdx.z
+    float* dst;                  // level images, z-th at dst + z*dst_zs
+    long long dst_zs;
     long long stride;  // bytes
     int w0, h0;
     int w, h, ld;
@@ -65,8 +111,8 @@ __global__ __launch_bounds__(256) void tw_pyr_level(PyrArgs a)
     float* rowbuf = pyr_sm + PYR_MAXK;   // [nrows][P]
     const int tid = threadIdx.x;
     const int x0 = blockIdx.x * PYR_TW, y0 = blockIdx.y * PYR_TH;
-    const uint8_t* __restrict__ src = a.src[blockIdx.z];
-    float* __restrict__ dst = a.dst[blockIdx.z];
+    const uint8_t* __restrict__ src = a.srcs[blockIdx.z];
+    float* __restrict__ dst = a.dst + blockIdx.z * a.dst_zs;
     const int ksize = a.ksize, r = ksize >> 1;
     const int P = (a.mode == 0) ? PYR_TW : 2 * PYR_TW;
 
@@ -160,10 +206,10 @@ struct PolyCoef {
 };
 
 struct PolyArgs {
-    const float* src[2];
-    float* dst[2];
+    const float* src;  // z-th image at src + z*ps
+    float* dst;        // z-th coefficient set (5 planes) at dst + z*5*ps
     int w, h, ld;
-    long long ps;  // plane stride (elements) of dst
+    long long ps;  // plane stride (elements)
     PolyCoef c;
 };
 
@@ -172,9 +218,11 @@ __global__ __launch_bounds__(256) void tw_polyexp(PolyArgs a)
 {
     __shared__ __attribute__((aligned(16))) float sm[3][PE_TH][PE_COLS];
     const int tid = threadIdx.x;
-    const int x0 = blockIdx.x * PE_TW, y0 = blockIdx.y * PE_TH;
-    const float* __restrict__ src = a.src[blockIdx.z];
-    float* __restrict__ dst = a.dst[blockIdx.z];
+    int bx, by, bz;
+    xcd_remap(bx, by, bz);
+    const int x0 = bx * PE_TW, y0 = by * PE_TH;
+    const float* __restrict__ src = a.src + bz * a.ps;
+    float* __restrict__ dst = a.dst + bz * 5 * a.ps;
     const PolyCoef& c = a.c;
 
     // ---- vertical pass: one column per thread, rows y0-N .. y0+TH-1+N in registers ----
@@ -342,14 +390,13 @@ __device__ __forceinline__ void update_matrices_px(const float* __restrict__ R0,
 //   otherwise the flow planes are read (zero-initialised at the coarsest level).
 // =====================================================================================================
 struct UpdArgs {
-    const float* R0;
-    const float* R1;
-    float* flow;  // 2 planes, plane stride fps
-    float* M;
+    const float* R;  // pair z: R0 = R + (2z)*5ps, R1 = R + (2z+1)*5ps
+    float* flow;     // pair z: 2 planes at flow + z*2*fps
+    float* M;        // pair z: 5 planes at M + z*5*ps
     int w, h, ld;
     long long ps, fps;
     // upsample source
-    const float* prev;  // 2 planes
+    const float* prev;  // pair z: 2 planes at prev + z*2*pfps
     int pw, ph, pld;
     long long pfps;
     const int* xofs;
@@ -368,14 +415,20 @@ __global__ __launch_bounds__(256) void tw_update_matrices(UpdArgs a)
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= a.w || y >= a.h) return;
     const long long o = (long long)y * a.ld + x;
+    const int z = blockIdx.z;
+    const float* __restrict__ R0 = a.R + (long long)(2 * z) * 5 * a.ps;
+    const float* __restrict__ R1 = R0 + 5 * a.ps;
+    float* __restrict__ flow = a.flow + (long long)z * 2 * a.fps;
+    float* __restrict__ Mo = a.M + (long long)z * 5 * a.ps;
     float dx, dy;
     if (UPSAMPLE) {
         const int sx = a.xofs[x];
         const int sy = a.yofs[y];
         const int r0 = clampi(sy, 0, a.ph - 1), r1 = clampi(sy + 1, 0, a.ph - 1);
         const float b0 = a.beta[2 * y], b1 = a.beta[2 * y + 1];
-        const float* P0 = a.prev + (long long)r0 * a.pld + sx;
-        const float* P1 = a.prev + (long long)r1 * a.pld + sx;
+        const float* __restrict__ prev = a.prev + (long long)z * 2 * a.pfps;
+        const float* P0 = prev + (long long)r0 * a.pld + sx;
+        const float* P1 = prev + (long long)r1 * a.pld + sx;
         float t0x, t1x, t0y, t1y;
         if (x < a.xmax) {
             const float a0 = a.alpha[2 * x], a1 = a.alpha[2 * x + 1];
@@ -391,20 +444,20 @@ __global__ __launch_bounds__(256) void tw_update_matrices(UpdArgs a)
         }
         dx = (t0x * b0 + t1x * b1) * a.scale + 0.f;
         dy = (t0y * b0 + t1y * b1) * a.scale + 0.f;
-        a.flow[o] = dx;
-        a.flow[o + a.fps] = dy;
+        flow[o] = dx;
+        flow[o + a.fps] = dy;
     } else if (a.zero_flow) {
         dx = dy = 0.f;
-        a.flow[o] = 0.f;
-        a.flow[o + a.fps] = 0.f;
+        flow[o] = 0.f;
+        flow[o + a.fps] = 0.f;
     } else {
-        dx = a.flow[o];
-        dy = a.flow[o + a.fps];
+        dx = flow[o];
+        dy = flow[o + a.fps];
     }
     float M[5];
-    update_matrices_px(a.R0, a.R1, a.ps, a.ld, a.w, a.h, x, y, dx, dy, M);
+    update_matrices_px(R0, R1, a.ps, a.ld, a.w, a.h, x, y, dx, dy, M);
 #pragma unroll
-    for (int c = 0; c < 5; c++) a.M[o + c * a.ps] = M[c];
+    for (int c = 0; c < 5; c++) Mo[o + c * a.ps] = M[c];
 }
 
 // =====================================================================================================
@@ -423,11 +476,10 @@ struct WinCoef {
 };
 
 struct BlurArgs {
-    const float* Min;
+    const float* Min;  // pair z at + z*5*ps
     float* Mout;
-    float* flow;
-    const float* R0;
-    const float* R1;
+    float* flow;     // pair z at + z*2*fps
+    const float* R;  // pair z: R0 = R + (2z)*5ps, R1 = R0 + 5ps
     int w, h, ld;
     long long ps, fps;
     int update;  // refresh M (i < iterations-1)
@@ -443,13 +495,19 @@ __global__ __launch_bounds__(COLS) void tw_blur_solve(BlurArgs a)
     const int tid = threadIdx.x;
     const int x0 = blockIdx.x * TW, y0 = blockIdx.y * BS_TH;
     const WinCoef& c = a.c;
+    const int z = blockIdx.z;
+    const float* __restrict__ Min = a.Min + (long long)z * 5 * a.ps;
+    float* __restrict__ Mout = a.Mout + (long long)z * 5 * a.ps;
+    float* __restrict__ flow = a.flow + (long long)z * 2 * a.fps;
+    const float* __restrict__ R0 = a.R + (long long)(2 * z) * 5 * a.ps;
+    const float* __restrict__ R1 = R0 + 5 * a.ps;
 
     // ---- vertical blur: one column per thread ----
     {
         const int x = clampi(x0 - HALO + tid, 0, a.w - 1);
 #pragma unroll 1
         for (int ch = 0; ch < 5; ch++) {
-            const float* __restrict__ Mp = a.Min + ch * a.ps + x;
+            const float* __restrict__ Mp = Min + ch * a.ps + x;
             float win[BS_TH + 2 * MH];
 #pragma unroll
             for (int i = 0; i < BS_TH + 2 * MH; i++) {
@@ -503,13 +561,259 @@ __global__ __launch_bounds__(COLS) void tw_blur_solve(BlurArgs a)
             const float fxv = (float)((g11 * h2 - g12 * h1) * idet);
             const float fyv = (float)((g22 * h1 - g12 * h2) * idet);
             const long long o = (long long)y * a.ld + x + j;
-            a.flow[o] = fxv;
-            a.flow[o + a.fps] = fyv;
+            flow[o] = fxv;
+            flow[o + a.fps] = fyv;
             if (a.update) {
                 float M[5];
-                update_matrices_px(a.R0, a.R1, a.ps, a.ld, a.w, a.h, x + j, y, fxv, fyv, M);
+                update_matrices_px(R0, R1, a.ps, a.ld, a.w, a.h, x + j, y, fxv, fyv, M);
 #pragma unroll
-                for (int cc = 0; cc < 5; cc++) a.Mout[o + cc * a.ps] = M[cc];
+                for (int cc = 0; cc < 5; cc++) Mout[o + cc * a.ps] = M[cc];
+            }
+        }
+    }
+}
+
+// -----------------------------------------------------------------------------------------------------
+// tw_blur_solve2<MH,COLS,HALO,TH,MINW> : the same arithmetic, tuned issue stream.
+//   * no fused matrix refresh (the refresh is a separate, high-occupancy gather kernel)
+//   * row bases are wave-uniform (SGPR) and the column is a 32-bit VGPR offset: loads need no VALU address math
+//   * TH rows per tile (9 divides 1080/540/270/135 and fills 504 of 512 horizontal work items)
+//   * __launch_bounds__(COLS, MINW) keeps the register budget at MINW waves per SIMD
+// -----------------------------------------------------------------------------------------------------
+template <int MH, int COLS, int HALO, int TH, int MINW>
+__global__ __launch_bounds__(COLS, MINW) void tw_blur_solve2(BlurArgs a)
+{
+    constexpr int TW = COLS - 2 * HALO;
+    __shared__ __attribute__((aligned(16))) float sm[5][TH][COLS];
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    const WinCoef& c = a.c;
+    const int z = blockIdx.z;
+    const float* __restrict__ Min = a.Min + (long long)z * 5 * a.ps;
+    float* __restrict__ flow = a.flow + (long long)z * 2 * a.fps;
+
+    // ---- vertical blur: one column per thread, rows y0-MH .. y0+TH-1+MH in a register window ----
+    {
+        const unsigned xb = (unsigned)clampi(x0 - HALO + tid, 0, a.w - 1) * 4u;
+        const bool interior = (y0 - MH >= 0) && (y0 + TH - 1 + MH <= a.h - 1);  // wave-uniform
+        const __amdgpu_buffer_rsrc_t rsM = make_rsrc(Min);
+        const unsigned ldb = (unsigned)a.ld * 4u, psb = (unsigned)(a.ps * 4);
+#pragma unroll 1
+        for (int ch = 0; ch < 5; ch++) {
+            float win[TH + 2 * MH];
+            if (interior) {
+                unsigned so = ch * psb + (unsigned)(y0 - MH) * ldb;
+#pragma unroll
+                for (int i = 0; i < TH + 2 * MH; i++) {
+                    win[i] = bload(rsM, xb, so);
+                    so += ldb;
+                }
+            } else {
+                int yy = y0 - MH;
+                unsigned so = ch * psb + (unsigned)clampi(yy, 0, a.h - 1) * ldb;
+#pragma unroll
+                for (int i = 0; i < TH + 2 * MH; i++) {
+                    win[i] = bload(rsM, xb, so);
+                    yy++;
+                    so += (yy > 0 && yy < a.h) ? ldb : 0u;  // replicate rows outside the image
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < TH; r++) {
+                float s0 = win[r + MH] * c.k[0];
+#pragma unroll
+                for (int i = 1; i <= MH; i++) s0 += (win[r + MH + i] + win[r + MH - i]) * c.k[i];
+                sm[ch][r][tid] = s0;
+                // rows are issued in order, two at a time: without this the scheduler interleaves all TH rows
+                // and keeps ~120 temporaries live (124 VGPRs instead of ~50 for this phase)
+                if (r & 1) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- horizontal blur + solve: items = TH rows x TW/4 groups of 4 pixels ----
+    constexpr int GROUPS = TW / 4;
+    constexpr int WL = 4 + 2 * HALO;
+#pragma unroll 1
+    for (int it = tid; it < TH * GROUPS; it += COLS) {
+        const int r = it / GROUPS, q = it - r * GROUPS;
+        const int y = y0 + r, x = x0 + 4 * q;
+        if (y >= a.h || x >= a.w) continue;
+        float hs[5][4];
+#pragma unroll
+        for (int ch = 0; ch < 5; ch++) {
+            float v[WL];
+#pragma unroll
+            for (int u = 0; u < WL / 4; u++) {
+                const f32x4 A = *(const f32x4*)&sm[ch][r][4 * q + 4 * u];
+                v[4 * u] = A[0];
+                v[4 * u + 1] = A[1];
+                v[4 * u + 2] = A[2];
+                v[4 * u + 3] = A[3];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int li = HALO + j;
+                float sum = v[li] * c.k[0];
+#pragma unroll
+                for (int i = 1; i <= MH; i++) sum += c.k[i] * (v[li - i] + v[li + i]);
+                hs[ch][j] = sum;
+                if (j & 1) __builtin_amdgcn_sched_barrier(0);  // two pixels in flight, one channel window live
+            }
+        }
+        float fxv[4], fyv[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const double g11 = hs[0][j], g12 = hs[1][j], g22 = hs[2][j], h1 = hs[3][j], h2 = hs[4][j];
+            const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
+            fxv[j] = (float)((g11 * h2 - g12 * h1) * idet);
+            fyv[j] = (float)((g22 * h1 - g12 * h2) * idet);
+        }
+        float* fo = flow + (long long)y * a.ld + x;
+        if (x + 3 < a.w) {
+            *(f32x4*)fo = f32x4{fxv[0], fxv[1], fxv[2], fxv[3]};
+            *(f32x4*)(fo + a.fps) = f32x4{fyv[0], fyv[1], fyv[2], fyv[3]};
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (x + j < a.w) {
+                    fo[j] = fxv[j];
+                    fo[j + a.fps] = fyv[j];
+                }
+        }
+    }
+}
+
+// -----------------------------------------------------------------------------------------------------
+// tw_blur_solve3<MH,COLS,HALO,TH,FUSED> : low-register-pressure structure (4 workgroups = 16 waves per CU).
+//   V  : vertical blur of the 5 planes, one column per thread, register window, raw buffer loads  -> LDS
+//   H  : per plane: every work item reads its 4+2*HALO window from LDS and forms 4 blurred pixels in
+//        registers; after a barrier the results overwrite the (no longer needed) vertical sums in place
+//   S  : one pixel per lane (lane-consecutive x: coalesced stores and gathers): 2x2 solve in double,
+//        flow store, and — FUSED — the FarnebackUpdateMatrices refresh of that pixel into Mout
+// -----------------------------------------------------------------------------------------------------
+template <int MH, int COLS, int HALO, int TH, bool FUSED>
+__global__ __launch_bounds__(COLS) void tw_blur_solve3(BlurArgs a)
+{
+    constexpr int TW = COLS - 2 * HALO;
+    __shared__ __attribute__((aligned(16))) float sm[5][TH][COLS];
+    const int tid = threadIdx.x;
+    int bx, by, z;
+    xcd_remap(bx, by, z);
+    const int x0 = bx * TW, y0 = by * TH;
+    const WinCoef& c = a.c;
+    const float* __restrict__ Min = a.Min + (long long)z * 5 * a.ps;
+    float* __restrict__ flow = a.flow + (long long)z * 2 * a.fps;
+
+    // ---- V: vertical blur, rows y0-MH .. y0+TH-1+MH of the thread's column in a register window ----
+    {
+        const unsigned xb = (unsigned)clampi(x0 - HALO + tid, 0, a.w - 1) * 4u;
+        const bool interior = (y0 - MH >= 0) && (y0 + TH - 1 + MH <= a.h - 1);  // wave-uniform
+        const __amdgpu_buffer_rsrc_t rsM = make_rsrc(Min);
+        const unsigned ldb = (unsigned)a.ld * 4u, psb = (unsigned)(a.ps * 4);
+#pragma unroll 1
+        for (int ch = 0; ch < 5; ch++) {
+            float win[TH + 2 * MH];
+            if (interior) {
+                unsigned so = ch * psb + (unsigned)(y0 - MH) * ldb;
+#pragma unroll
+                for (int i = 0; i < TH + 2 * MH; i++) {
+                    win[i] = bload(rsM, xb, so);
+                    so += ldb;
+                }
+            } else {
+                int yy = y0 - MH;
+                unsigned so = ch * psb + (unsigned)clampi(yy, 0, a.h - 1) * ldb;
+#pragma unroll
+                for (int i = 0; i < TH + 2 * MH; i++) {
+                    win[i] = bload(rsM, xb, so);
+                    yy++;
+                    so += (yy > 0 && yy < a.h) ? ldb : 0u;  // replicate rows outside the image
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < TH; r++) {
+                float s0 = win[r + MH] * c.k[0];
+#pragma unroll
+                for (int i = 1; i <= MH; i++) s0 += (win[r + MH + i] + win[r + MH - i]) * c.k[i];
+                sm[ch][r][tid] = s0;
+                // rows are issued in order, two at a time (otherwise all TH rows are interleaved and ~120
+                // temporaries stay live)
+                if (r & 1) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- H: horizontal blur, in place ----
+    constexpr int GROUPS = TW / 4;
+    constexpr int NITEM = TH * GROUPS;
+    constexpr int ROUNDS = (NITEM + COLS - 1) / COLS;
+    constexpr int WL = 4 + 2 * HALO;
+#pragma unroll 1
+    for (int ch = 0; ch < 5; ch++) {
+        f32x4 res[ROUNDS];
+#pragma unroll
+        for (int rd = 0; rd < ROUNDS; rd++) {
+            const int it = tid + rd * COLS;
+            if (it < NITEM) {
+                const int r = it / GROUPS, q = it - r * GROUPS;
+                float v[WL];
+#pragma unroll
+                for (int u = 0; u < WL / 4; u++) {
+                    const f32x4 A = *(const f32x4*)&sm[ch][r][4 * q + 4 * u];
+                    v[4 * u] = A[0];
+                    v[4 * u + 1] = A[1];
+                    v[4 * u + 2] = A[2];
+                    v[4 * u + 3] = A[3];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int li = HALO + j;
+                    float sum = v[li] * c.k[0];
+#pragma unroll
+                    for (int i = 1; i <= MH; i++) sum += c.k[i] * (v[li - i] + v[li + i]);
+                    res[rd][j] = sum;
+                    if (j & 1) __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        __syncthreads();  // every window of this plane has been read: its interior may be overwritten
+#pragma unroll
+        for (int rd = 0; rd < ROUNDS; rd++) {
+            const int it = tid + rd * COLS;
+            if (it < NITEM) {
+                const int r = it / GROUPS, q = it - r * GROUPS;
+                *(f32x4*)&sm[ch][r][HALO + 4 * q] = res[rd];
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- S: solve (+ refresh), one pixel per lane ----
+    float* __restrict__ Mout = a.Mout + (long long)z * 5 * a.ps;
+    const float* __restrict__ R0 = a.R + (long long)(2 * z) * 5 * a.ps;
+    const float* __restrict__ R1 = R0 + 5 * a.ps;
+#pragma unroll 1
+    for (int p = tid; p < TH * TW; p += COLS) {
+        const int r = p / TW, cx = p - r * TW;
+        const int x = x0 + cx, y = y0 + r;
+        if (x >= a.w || y >= a.h) continue;
+        const double g11 = sm[0][r][HALO + cx], g12 = sm[1][r][HALO + cx], g22 = sm[2][r][HALO + cx],
+                     h1 = sm[3][r][HALO + cx], h2 = sm[4][r][HALO + cx];
+        const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
+        const float fxv = (float)((g11 * h2 - g12 * h1) * idet);
+        const float fyv = (float)((g22 * h1 - g12 * h2) * idet);
+        const long long o = (long long)y * a.ld + x;
+        flow[o] = fxv;
+        flow[o + a.fps] = fyv;
+        if (FUSED) {
+            if (a.update) {
+                float M[5];
+                update_matrices_px(R0, R1, a.ps, a.ld, a.w, a.h, x, y, fxv, fyv, M);
+#pragma unroll
+                for (int cc = 0; cc < 5; cc++) Mout[o + cc * a.ps] = M[cc];
             }
         }
     }
@@ -524,13 +828,19 @@ __global__ __launch_bounds__(256) void tw_blur_solve_generic(BlurArgs a)
     const int CW = 64 + 2 * m;
     const int tid = threadIdx.x;
     const int x0 = blockIdx.x * 64, y0 = blockIdx.y * BS_TH;
+    const int z = blockIdx.z;
+    const float* __restrict__ Min = a.Min + (long long)z * 5 * a.ps;
+    float* __restrict__ Mout = a.Mout + (long long)z * 5 * a.ps;
+    float* __restrict__ flow = a.flow + (long long)z * 2 * a.fps;
+    const float* __restrict__ R0 = a.R + (long long)(2 * z) * 5 * a.ps;
+    const float* __restrict__ R1 = R0 + 5 * a.ps;
     for (int it = tid; it < 5 * BS_TH * CW; it += 256) {
         const int ch = it / (BS_TH * CW);
         const int rem = it - ch * BS_TH * CW;
         const int r = rem / CW, cix = rem - r * CW;
         const int x = clampi(x0 - m + cix, 0, a.w - 1);
         const int y = y0 + r;
-        const float* __restrict__ Mp = a.Min + ch * a.ps + x;
+        const float* __restrict__ Mp = Min + ch * a.ps + x;
         float s0 = Mp[(long long)clampi(y, 0, a.h - 1) * a.ld] * a.c.k[0];
         for (int i = 1; i <= m; i++)
             s0 += (Mp[(long long)clampi(y + i, 0, a.h - 1) * a.ld] + Mp[(long long)clampi(y - i, 0, a.h - 1) * a.ld]) *
@@ -554,12 +864,12 @@ __global__ __launch_bounds__(256) void tw_blur_solve_generic(BlurArgs a)
         const float fxv = (float)((g11 * h2 - g12 * h1) * idet);
         const float fyv = (float)((g22 * h1 - g12 * h2) * idet);
         const long long o = (long long)y * a.ld + x;
-        a.flow[o] = fxv;
-        a.flow[o + a.fps] = fyv;
+        flow[o] = fxv;
+        flow[o + a.fps] = fyv;
         if (a.update) {
             float M[5];
-            update_matrices_px(a.R0, a.R1, a.ps, a.ld, a.w, a.h, x, y, fxv, fyv, M);
-            for (int cc = 0; cc < 5; cc++) a.Mout[o + cc * a.ps] = M[cc];
+            update_matrices_px(R0, R1, a.ps, a.ld, a.w, a.h, x, y, fxv, fyv, M);
+            for (int cc = 0; cc < 5; cc++) Mout[o + cc * a.ps] = M[cc];
         }
     }
 }
@@ -567,63 +877,91 @@ __global__ __launch_bounds__(256) void tw_blur_solve_generic(BlurArgs a)
 // =====================================================================================================
 // K12  tw_span_scan : the span-grid threshold scan of /root/reference/src/consumer.cpp:60-76.
 //   len = dx*dx + dy*dy in float, compared in double against threshold*threshold (strict >);
-//   flagged grid vectors are compacted in the reference's row-major order by one 1024-thread workgroup
-//   (count -> LDS scan -> ordered write), so only the hits cross PCIe.
+//   flagged grid vectors are compacted in the reference's row-major order (y, then x) so that only the
+//   hits cross PCIe.  One 1024-thread workgroup per image pair (blockIdx.x); grid points are visited
+//   1024 at a time (lane-consecutive points), order is restored with wave ballots + one LDS scan of the
+//   per-wave counts per round of 32 x 1024 points.
 // =====================================================================================================
 struct ScanRec {
     int x, y;
     float dx, dy;
 };
 struct ScanArgs {
-    const float* flow;
-    long long fps;
+    const float* flow;  // pair z: 2 planes at flow + z*fzs
+    long long fzs, fps;
     int w, h, ld;
     int span, gw, gh;
     double thr2;
-    int* count;    // [1]
-    ScanRec* rec;  // [gw*gh]
+    int* count;    // [pairs]
+    ScanRec* rec;  // pair z at rec + z*rec_zs
+    long long rec_zs;
 };
+
+constexpr int SCAN_IT = 32;  // iterations of 1024 points per round
 
 __global__ __launch_bounds__(1024) void tw_span_scan(ScanArgs a)
 {
-    __shared__ int part[1024];
-    const int tid = threadIdx.x;
+    __shared__ int wsum[SCAN_IT * 16];
+    __shared__ int round_total;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int z = blockIdx.x;
+    const float* __restrict__ fxp = a.flow + (long long)z * a.fzs;
+    const float* __restrict__ fyp = fxp + a.fps;
+    ScanRec* __restrict__ rec = a.rec + (long long)z * a.rec_zs;
     const int G = a.gw * a.gh;
-    const int per = (G + 1023) / 1024;
-    const int b = tid * per, e = min(b + per, G);
-    int cnt = 0;
-    for (int i = b; i < e; i++) {
-        const int gy = i / a.gw, gx = i - gy * a.gw;
-        const long long o = (long long)(gy * a.span) * a.ld + gx * a.span;
-        const float dx = a.flow[o], dy = a.flow[o + a.fps];
-        const float len = (dx * dx) + (dy * dy);
-        cnt += ((double)len > a.thr2) ? 1 : 0;
-    }
-    part[tid] = cnt;
-    __syncthreads();
-    // Hillis-Steele inclusive scan over 1024 partial counts
-    for (int off = 1; off < 1024; off <<= 1) {
-        int v = (tid >= off) ? part[tid - off] : 0;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
-    }
-    int pos = part[tid] - cnt;
-    if (tid == 1023) a.count[0] = part[1023];
-    for (int i = b; i < e; i++) {
-        const int gy = i / a.gw, gx = i - gy * a.gw;
-        const long long o = (long long)(gy * a.span) * a.ld + gx * a.span;
-        const float dx = a.flow[o], dy = a.flow[o + a.fps];
-        const float len = (dx * dx) + (dy * dy);
-        if ((double)len > a.thr2) {
-            ScanRec rr;
-            rr.x = gx * a.span;
-            rr.y = gy * a.span;
-            rr.dx = dx;
-            rr.dy = dy;
-            a.rec[pos++] = rr;
+    int base_out = 0;
+    for (int base = 0; base < G; base += SCAN_IT * 1024) {
+        const int nit = min(SCAN_IT, (G - base + 1023) / 1024);
+        unsigned mask = 0;
+        for (int i = 0; i < nit; i++) {
+            const int idx = base + i * 1024 + tid;
+            bool f = false;
+            if (idx < G) {
+                const int gy = idx / a.gw, gx = idx - gy * a.gw;
+                const long long o = (long long)(gy * a.span) * a.ld + gx * a.span;
+                const float dx = fxp[o], dy = fyp[o];
+                const float len = (dx * dx) + (dy * dy);
+                f = (double)len > a.thr2;
+            }
+            const unsigned long long b = __ballot(f);
+            if (lane == 0) wsum[i * 16 + wave] = __popcll(b);
+            mask |= f ? (1u << i) : 0u;
         }
+        __syncthreads();
+        // exclusive scan of the nit*16 per-wave counts (<= 512 entries) in place
+        const int ne = nit * 16;
+        int mine = (tid < ne) ? wsum[tid] : 0;
+        int incl = mine;
+        for (int off = 1; off < 512; off <<= 1) {
+            __syncthreads();
+            if (tid < ne) wsum[tid] = incl;
+            __syncthreads();
+            if (tid < ne && tid >= off) incl += wsum[tid - off];
+        }
+        __syncthreads();
+        if (tid < ne) wsum[tid] = incl - mine;
+        if (tid == ne - 1) round_total = incl;
+        __syncthreads();
+        for (int i = 0; i < nit; i++) {
+            const bool f = (mask >> i) & 1u;
+            const unsigned long long b = __ballot(f);
+            if (f) {
+                const int idx = base + i * 1024 + tid;
+                const int gy = idx / a.gw, gx = idx - gy * a.gw;
+                const long long o = (long long)(gy * a.span) * a.ld + gx * a.span;
+                const int pos = base_out + wsum[i * 16 + wave] + __popcll(b & ((1ull << lane) - 1ull));
+                ScanRec rr;
+                rr.x = gx * a.span;
+                rr.y = gy * a.span;
+                rr.dx = fxp[o];
+                rr.dy = fyp[o];
+                rec[pos] = rr;
+            }
+        }
+        base_out += round_total;
+        __syncthreads();
     }
+    if (tid == 0) a.count[z] = base_out;
 }
 
 }  // namespace twk

@@ -46,9 +46,9 @@ _lib = None
 # every symbol include/twflow.h declares
 SYMBOLS = [
     "tw_default_params", "tw_device_count", "tw_engine_create", "tw_engine_destroy", "tw_strerror",
-    "tw_last_error", "tw_flow_u8", "tw_diff_u8", "tw_submit_u8", "tw_submit_dev", "tw_wait",
+    "tw_last_error", "tw_flow_u8", "tw_diff_u8", "tw_submit_u8", "tw_submit_dev", "tw_flush", "tw_wait",
     "tw_grid_capacity", "tw_dev_alloc", "tw_dev_free", "tw_dev_upload", "tw_prof_select", "tw_prof_read",
-    "tw_algorithmic_bytes", "tw_algorithmic_bytes_pair", "tw_num_levels", "tw_stage_pyr_level",
+    "tw_algorithmic_bytes", "tw_algorithmic_bytes_pair", "tw_num_levels", "tw_level_chunk", "tw_bench_stage", "tw_stage_pyr_level",
     "tw_stage_polyexp", "tw_stage_update_matrices", "tw_stage_flow_upsample_update", "tw_stage_blur_solve",
 ]
 
@@ -80,6 +80,9 @@ def lib():
     L.tw_submit_dev.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_ssize_t, C.c_int, C.c_double,
                                 C.POINTER(C.c_int64)]
     L.tw_wait.argtypes = [vp, C.c_int64, C.POINTER(Vector), C.c_int, ip, fp]
+    L.tw_flush.argtypes = [vp]
+    L.tw_bench_stage.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fp]
+    L.tw_level_chunk.argtypes = [vp, C.c_int, C.c_int, C.c_int]
     L.tw_grid_capacity.argtypes = [C.c_int, C.c_int, C.c_int]
     L.tw_dev_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
     L.tw_dev_free.argtypes = [vp, vp]
@@ -209,6 +212,18 @@ class Engine:
         tk = C.c_int64()
         self._check(self._L.tw_submit_dev(self._h, d_expect, d_target, w, h, stride, span, threshold, C.byref(tk)))
         return (tk.value, w, h, span, threshold)
+
+    def bench_stage(self, kclass, w, h, level, npairs=1, iters=20, flags=0):
+        """Average microseconds per launch of one kernel class on synthetic resident data."""
+        us = C.c_float()
+        self._check(self._L.tw_bench_stage(self._h, kclass, w, h, level, npairs, iters, flags, C.byref(us)))
+        return us.value
+
+    def flush(self):
+        self._check(self._L.tw_flush(self._h))
+
+    def level_chunk(self, w, h, level):
+        return self._L.tw_level_chunk(self._h, w, h, level)
 
     def wait(self, ticket):
         tk, w, h, span, threshold = ticket

@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Isolated per-kernel timings (tw_bench_stage) at 1080p: microseconds per launch and algorithmic GB/s."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tidal-wave_amd"))
+import twflow as T  # noqa: E402
+
+W, H = 1920, 1080
+
+
+def main():
+    iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+    only = int(sys.argv[2]) if len(sys.argv) > 2 else -1      # kernel class
+    only_lv = int(sys.argv[3]) if len(sys.argv) > 3 else -1   # level
+    only_flags = int(sys.argv[4]) if len(sys.argv) > 4 else -1
+    with T.Engine(0, T.default_params(), slots=64) as e:
+        L = e.num_levels(W, H)
+        print("%-20s %5s %6s %10s %10s %8s" % ("kernel", "level", "pairs", "us/launch", "us/pair", "GB/s"))
+        for kc in (T.K_PYR, T.K_POLYEXP, T.K_UPDATE_MATRICES, T.K_BLUR_SOLVE, T.K_SCAN):
+            if only >= 0 and kc != only:
+                continue
+            for lv in range(0, L + 1):
+                if kc == T.K_SCAN and lv > 0:
+                    continue
+                if only_lv >= 0 and lv != only_lv:
+                    continue
+                n = e.level_chunk(W, H, lv)
+                for flags in ((0, 2) if kc == T.K_BLUR_SOLVE else (0,)):
+                    if only_flags >= 0 and flags != only_flags:
+                        continue
+                    us = e.bench_stage(kc, W, H, lv, n, iters, flags)
+                    b = e.algorithmic_bytes(kc, lv, W, H) * n
+                    if kc == T.K_BLUR_SOLVE:
+                        w, h = W >> lv, H >> lv
+                        b = (28 + (0 if flags & 2 else 68)) * w * h * n
+                    name = T.KERNEL_NAMES[kc] + ("(no refresh)" if flags & 2 else "")
+                    print("%-20s %5d %6d %10.1f %10.2f %8.0f" % (name[:20], lv, n, us, us / n, b / us / 1e3 if b else 0))
+
+
+if __name__ == "__main__":
+    main()
