@@ -276,7 +276,7 @@ struct tw_engine {
     PolyCoef pc;
     WinCoef wc;
     int win_m = 15;
-    int blur_variant = 5;  // 5: v3 structure with the refresh fused into the solve phase (default); 4: v3 + separate refresh; 0-3: earlier structures kept for A/B
+    int blur_variant = 6;  // 6: v4 structure, refresh fused into the solve phase (default); 7: v4 + separate refresh; 0-5, 8-10: earlier structures / ILP sweeps kept for A/B
     std::string err;
     // device workspace, shared by all batches (execution is ordered on one stream)
     size_t ws_elems = 0;                 // capacity of I (floats); R = 5x, M = 5x each
@@ -632,7 +632,29 @@ void launch_blur(tw_engine* e, hipStream_t st, int w, int h, int ld, long long p
     bool fused = true;
     {
         ProfScope pscope(e, st, TW_K_BLUR_SOLVE, level);
-        if (e->win_m == 15 && (e->blur_variant == 4 || e->blur_variant == 5)) {
+        if (e->win_m == 15 && e->blur_variant >= 8 && e->blur_variant <= 10) {
+            // ILP sweeps of the v4 structure (fused refresh)
+            if (e->blur_variant == 8) {
+                if (wide) hipLaunchKernelGGL((tw_blur_solve4<15, 256, 16, 8, true, 4, 4>), dim3((w + 223) / 224, gy, npairs), dim3(256), 0, st, a);
+                else hipLaunchKernelGGL((tw_blur_solve4<15, 128, 16, 8, true, 4, 4>), dim3((w + 95) / 96, gy, npairs), dim3(128), 0, st, a);
+            } else if (e->blur_variant == 9) {
+                if (wide) hipLaunchKernelGGL((tw_blur_solve4<15, 256, 16, 8, true, 8, 4>), dim3((w + 223) / 224, gy, npairs), dim3(256), 0, st, a);
+                else hipLaunchKernelGGL((tw_blur_solve4<15, 128, 16, 8, true, 8, 4>), dim3((w + 95) / 96, gy, npairs), dim3(128), 0, st, a);
+            } else {
+                if (wide) hipLaunchKernelGGL((tw_blur_solve4<15, 256, 16, 8, true, 1, 1>), dim3((w + 223) / 224, gy, npairs), dim3(256), 0, st, a);
+                else hipLaunchKernelGGL((tw_blur_solve4<15, 128, 16, 8, true, 1, 1>), dim3((w + 95) / 96, gy, npairs), dim3(128), 0, st, a);
+            }
+        } else if (e->win_m == 15 && (e->blur_variant == 6 || e->blur_variant == 7)) {
+            // v4 structure: 6 = refresh fused, 7 = separate refresh kernel
+            if (e->blur_variant == 7) {
+                fused = false;
+                if (wide) hipLaunchKernelGGL((tw_blur_solve4<15, 256, 16, 8, false>), dim3((w + 223) / 224, gy, npairs), dim3(256), 0, st, a);
+                else hipLaunchKernelGGL((tw_blur_solve4<15, 128, 16, 8, false>), dim3((w + 95) / 96, gy, npairs), dim3(128), 0, st, a);
+            } else {
+                if (wide) hipLaunchKernelGGL((tw_blur_solve4<15, 256, 16, 8, true>), dim3((w + 223) / 224, gy, npairs), dim3(256), 0, st, a);
+                else hipLaunchKernelGGL((tw_blur_solve4<15, 128, 16, 8, true>), dim3((w + 95) / 96, gy, npairs), dim3(128), 0, st, a);
+            }
+        } else if (e->win_m == 15 && (e->blur_variant == 4 || e->blur_variant == 5)) {
             // v3 structure: 4 = separate refresh kernel, 5 = refresh fused into the solve phase
             if (e->blur_variant == 4) {
                 fused = false;

@@ -819,6 +819,136 @@ __global__ __launch_bounds__(COLS) void tw_blur_solve3(BlurArgs a)
     }
 }
 
+// -----------------------------------------------------------------------------------------------------
+// tw_blur_solve4<MH,COLS,HALO,TH,FUSED> : v3 with the stalls taken out.
+//   * the TH+2*MH clamped row offsets are computed once (SGPRs); the plane is selected by rebasing the buffer
+//     resource, so the vertical phase issues no address arithmetic at all
+//   * the next plane's register window is loaded while the current plane is being blurred (two windows)
+//   * the horizontal results of all 5 planes stay in registers: 3 workgroup barriers instead of 7
+//   * solve / refresh phase handles two pixels per step (more gathers in flight per lane)
+// -----------------------------------------------------------------------------------------------------
+template <int MH, int COLS, int HALO, int TH, bool FUSED, int VILP = 2, int HILP = 2>
+__global__ __launch_bounds__(COLS) void tw_blur_solve4(BlurArgs a)
+{
+    constexpr int TW = COLS - 2 * HALO;
+    constexpr int NW = TH + 2 * MH;
+    __shared__ __attribute__((aligned(16))) float sm[5][TH][COLS];
+    const int tid = threadIdx.x;
+    int bx, by, z;
+    xcd_remap(bx, by, z);
+    const int x0 = bx * TW, y0 = by * TH;
+    const WinCoef& c = a.c;
+    const float* __restrict__ Min = a.Min + (long long)z * 5 * a.ps;
+    float* __restrict__ flow = a.flow + (long long)z * 2 * a.fps;
+
+    // ---- V ----
+    {
+        const unsigned xb = (unsigned)clampi(x0 - HALO + tid, 0, a.w - 1) * 4u;
+        unsigned ro[NW];  // wave-uniform byte offsets of the clamped rows
+#pragma unroll
+        for (int i = 0; i < NW; i++) ro[i] = (unsigned)clampi(y0 - MH + i, 0, a.h - 1) * ((unsigned)a.ld * 4u);
+        float wa[NW], wb[NW];
+        {
+            const __amdgpu_buffer_rsrc_t rs = make_rsrc(Min);
+#pragma unroll
+            for (int i = 0; i < NW; i++) wa[i] = bload(rs, xb, ro[i]);
+        }
+#pragma unroll
+        for (int ch = 0; ch < 5; ch++) {
+            float* cur = (ch & 1) ? wb : wa;
+            float* nxt = (ch & 1) ? wa : wb;
+            if (ch < 4) {
+                const __amdgpu_buffer_rsrc_t rs = make_rsrc(Min + (long long)(ch + 1) * a.ps);
+#pragma unroll
+                for (int i = 0; i < NW; i++) nxt[i] = bload(rs, xb, ro[i]);
+            }
+#pragma unroll
+            for (int r = 0; r < TH; r++) {
+                float s0 = cur[r + MH] * c.k[0];
+#pragma unroll
+                for (int i = 1; i <= MH; i++) s0 += (cur[r + MH + i] + cur[r + MH - i]) * c.k[i];
+                sm[ch][r][tid] = s0;
+                if ((r & (VILP - 1)) == VILP - 1) __builtin_amdgcn_sched_barrier(0);  // VILP rows in flight
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- H: all planes, results in registers ----
+    constexpr int GROUPS = TW / 4;
+    constexpr int NITEM = TH * GROUPS;
+    constexpr int ROUNDS = (NITEM + COLS - 1) / COLS;
+    constexpr int WL = 4 + 2 * HALO;
+    f32x4 res[ROUNDS][5];
+#pragma unroll
+    for (int rd = 0; rd < ROUNDS; rd++) {
+        const int it = tid + rd * COLS;
+        if (it < NITEM) {
+            const int r = it / GROUPS, q = it - r * GROUPS;
+#pragma unroll
+            for (int ch = 0; ch < 5; ch++) {
+                float v[WL];
+#pragma unroll
+                for (int u = 0; u < WL / 4; u++) {
+                    const f32x4 A = *(const f32x4*)&sm[ch][r][4 * q + 4 * u];
+                    v[4 * u] = A[0];
+                    v[4 * u + 1] = A[1];
+                    v[4 * u + 2] = A[2];
+                    v[4 * u + 3] = A[3];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int li = HALO + j;
+                    float sum = v[li] * c.k[0];
+#pragma unroll
+                    for (int i = 1; i <= MH; i++) sum += c.k[i] * (v[li - i] + v[li + i]);
+                    res[rd][ch][j] = sum;
+                    if ((j & (HILP - 1)) == HILP - 1) __builtin_amdgcn_sched_barrier(0);  // HILP pixels in flight
+                }
+            }
+        }
+    }
+    __syncthreads();  // every window has been read: the interiors may be overwritten
+#pragma unroll
+    for (int rd = 0; rd < ROUNDS; rd++) {
+        const int it = tid + rd * COLS;
+        if (it < NITEM) {
+            const int r = it / GROUPS, q = it - r * GROUPS;
+#pragma unroll
+            for (int ch = 0; ch < 5; ch++) *(f32x4*)&sm[ch][r][HALO + 4 * q] = res[rd][ch];
+        }
+    }
+    __syncthreads();
+
+    // ---- S: solve (+ refresh), lane-consecutive pixels ----
+    float* __restrict__ Mout = a.Mout + (long long)z * 5 * a.ps;
+    const float* __restrict__ R0 = a.R + (long long)(2 * z) * 5 * a.ps;
+    const float* __restrict__ R1 = R0 + 5 * a.ps;
+    static_assert((TH * TW) % COLS == 0, "pixels per lane must be whole");
+#pragma unroll 2
+    for (int p = tid; p < TH * TW; p += COLS) {
+        const int r = p / TW, cx = p - r * TW;
+        const int x = x0 + cx, y = y0 + r;
+        if (x >= a.w || y >= a.h) continue;
+        const double g11 = sm[0][r][HALO + cx], g12 = sm[1][r][HALO + cx], g22 = sm[2][r][HALO + cx],
+                     h1 = sm[3][r][HALO + cx], h2 = sm[4][r][HALO + cx];
+        const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
+        const float fxv = (float)((g11 * h2 - g12 * h1) * idet);
+        const float fyv = (float)((g22 * h1 - g12 * h2) * idet);
+        const long long o = (long long)y * a.ld + x;
+        flow[o] = fxv;
+        flow[o + a.fps] = fyv;
+        if (FUSED) {
+            if (a.update) {
+                float M[5];
+                update_matrices_px(R0, R1, a.ps, a.ld, a.w, a.h, x, y, fxv, fyv, M);
+#pragma unroll
+                for (int cc = 0; cc < 5; cc++) Mout[o + cc * a.ps] = M[cc];
+            }
+        }
+    }
+}
+
 // Generic window size (any m <= 32): same arithmetic, runtime loops, one pixel per thread, no register
 // window.  Slow path for non-default winSize.
 __global__ __launch_bounds__(256) void tw_blur_solve_generic(BlurArgs a)
