@@ -217,6 +217,8 @@ struct LevelPlan {
     int *d_xofs = nullptr, *d_yofs = nullptr;
     float *d_alpha = nullptr, *d_beta = nullptr, *d_kern = nullptr;
     int mode = 1, xmax = 0, nrows_max = 0;
+    float h_kern[3] = {0, 0, 0};  // host copy of the taps when ksize == 3
+    int pitch_b = 0;              // staged-row pitch (bytes) of tw_pyr_level_lds, 0: does not fit LDS
     // flow upsample tables (level k+1 -> k)
     int *d_uxofs = nullptr, *d_uyofs = nullptr;
     float *d_ualpha = nullptr, *d_ubeta = nullptr;
@@ -276,6 +278,8 @@ struct tw_engine {
     PolyCoef pc;
     WinCoef wc;
     int win_m = 15;
+    int img_aligned4 = 0;  // every image pointer and the row stride of the batch being enqueued are 4-byte aligned
+    int pyr_generic = 0;   // TW_PYR_GENERIC=1: always the generic pyramid kernel (A/B, parity cross-check)
     int blur_variant = 6;  // 6: v4 structure, refresh fused into the solve phase (default); 7: v4 + separate refresh; 0-5, 8-10: earlier structures / ILP sweeps kept for A/B
     std::string err;
     // device workspace, shared by all batches (execution is ordered on one stream)
@@ -288,6 +292,7 @@ struct tw_engine {
     const uint8_t** d_ptrs = nullptr;  // [2*cap]
     int* d_count = nullptr;            // [cap]
     ScanRec* d_rec = nullptr;          // [cap][G]
+    float2* d_grid = nullptr;          // [cap][G] dense grid samples (dx,dy)
     size_t d_rec_cap = 0;
     // profiling: per kernel class, -2 = off, -1 = every level, k = level k only
     int prof_level[TW_K_COUNT] = {-2, -2, -2, -2, -2};
@@ -305,6 +310,8 @@ namespace {
             return _err == hipErrorOutOfMemory ? TW_E_NOMEM : TW_E_DEVICE;                \
         }                                                                                 \
     } while (0)
+
+size_t staged_image_bytes(int w, int h);
 
 template <typename T>
 tw_status upload_vec(tw_engine* e, Plan* pl, const std::vector<T>& v, T** out)
@@ -401,6 +408,7 @@ tw_status get_plan(tw_engine* e, int w0, int h0, Plan** out)
         gaussian_kernel(L.ksize, L.sigma, kern);
         L.mode = t.mode;
         L.xmax = t.xmax;
+        if (L.ksize == 3) memcpy(L.h_kern, kern.data(), sizeof(L.h_kern));
         L.nrows_max = pyr_nrows_max(t, L.h, h0, L.ksize / 2);
         const size_t lds = (size_t)(PYR_MAXK + (size_t)L.nrows_max * (t.mode == 0 ? PYR_TW : 2 * PYR_TW)) * 4;
         if (lds > 160 * 1024) {
@@ -408,6 +416,21 @@ tw_status get_plan(tw_engine* e, int w0, int h0, Plan** out)
             free_plan(pl);
             return TW_E_UNSUPPORTED;
         }
+        {
+            // widest staged source span over the tiles of this level (same formulas as the kernel)
+            const int r = L.ksize / 2;
+            int span = 0;
+            for (int x0 = 0; x0 < L.w; x0 += PYR_TW) {
+                const int xl = std::min(x0, L.w - 1), xr = std::min(x0 + PYR_TW - 1, L.w - 1);
+                const int Xfirst = t.mode == 0 ? xl : t.xofs[xl];
+                const int Xlast = t.mode == 0 ? xr : t.xofs[xr] + 1;
+                const int xlo_a = (Xfirst - r) & ~3;
+                span = std::max(span, ((Xlast + r - xlo_a) / 4 + 1) * 4);
+            }
+            const size_t lds2 = lds + (size_t)L.nrows_max * span;
+            L.pitch_b = (lds2 <= 64 * 1024 && L.ksize <= 63) ? span : 0;
+        }
+
         tw_status s;
         if ((s = upload_vec(e, pl, t.xofs, &L.d_xofs)) || (s = upload_vec(e, pl, t.yofs, &L.d_yofs)) ||
             (s = upload_vec(e, pl, t.alpha, &L.d_alpha)) || (s = upload_vec(e, pl, t.beta, &L.d_beta)) ||
@@ -449,7 +472,7 @@ tw_status reserve_workspace(tw_engine* e, const Plan* pl, int span, bool need_im
             const size_t fc = (size_t)pl->lv[k].ps * 2 * (k == 0 ? pl->lv[0].chunk : e->cap);
             if (fc > e->flow_cap[k]) grow = true;
         }
-    const size_t img = (size_t)pl->w0 * pl->h0 * 2 * e->cap;
+    const size_t img = staged_image_bytes(pl->w0, pl->h0) * 2 * e->cap;
     const size_t G = span > 0 ? (size_t)tw_grid_capacity(pl->w0, pl->h0, span) : 0;
     if (need_img && img > e->d_img_cap) grow = true;
     if (G * e->cap > e->d_rec_cap) grow = true;
@@ -491,8 +514,11 @@ tw_status reserve_workspace(tw_engine* e, const Plan* pl, int span, bool need_im
     }
     if (G * e->cap > e->d_rec_cap) {
         if (e->d_rec) (void)hipFree(e->d_rec);
+        if (e->d_grid) (void)hipFree(e->d_grid);
         e->d_rec = nullptr;
+        e->d_grid = nullptr;
         e->d_rec_cap = 0;
+        TW_HIP(e, hipMalloc((void**)&e->d_grid, G * e->cap * sizeof(float2) + 256));
         TW_HIP(e, hipMalloc((void**)&e->d_rec, G * e->cap * sizeof(ScanRec) + 256));
         e->d_rec_cap = G * e->cap;
     }
@@ -564,6 +590,33 @@ void launch_pyr(tw_engine* e, hipStream_t st, const Plan* pl, int k, const uint8
     const size_t lds = (size_t)(PYR_MAXK + (size_t)L.nrows_max * P) * 4;
     dim3 grid((L.w + PYR_TW - 1) / PYR_TW, (L.h + PYR_TH - 1) / PYR_TH, nimg);
     ProfScope ps(e, st, TW_K_PYR, k);
+    if (L.ksize == 3 && (L.mode == 0 || L.mode == 2) && pl->w0 >= 16 && !e->pyr_generic) {
+        // register-only fast path (3 taps, same-size or exact 2x2 area resize)
+        PyrK3Args b;
+        b.srcs = d_srcs;
+        b.dst = I;
+        b.dst_zs = L.ps;
+        b.stride = stride;
+        b.w0 = pl->w0;
+        b.h0 = pl->h0;
+        b.w = L.w;
+        b.h = L.h;
+        b.ld = L.ld;
+        b.k0 = L.h_kern[1];
+        b.k1 = L.h_kern[0];
+        b.aligned4 = (stride % 4 == 0) ? e->img_aligned4 : 0;
+        if (L.mode == 0) hipLaunchKernelGGL(tw_pyr_k3<0>, dim3((L.w + 255) / 256, (L.h + 7) / 8, nimg), dim3(256), 0, st, b);
+        else hipLaunchKernelGGL(tw_pyr_k3<2>, dim3((L.w + 255) / 256, (L.h + 3) / 4, nimg), dim3(256), 0, st, b);
+        return;
+    }
+    if (L.pitch_b > 0 && !e->pyr_generic) {
+        PyrLdsArgs b;
+        b.p = a;
+        b.pitch_b = L.pitch_b;
+        b.aligned4 = (stride % 4 == 0) ? e->img_aligned4 : 0;
+        hipLaunchKernelGGL(tw_pyr_level_lds, grid, dim3(256), lds + (size_t)L.nrows_max * L.pitch_b, st, b);
+        return;
+    }
     hipLaunchKernelGGL(tw_pyr_level, grid, dim3(256), lds, st, a);
 }
 
@@ -738,12 +791,13 @@ tw_status flush_ctx(tw_engine* e, Ctx& c)
     if (r) return r;
     if ((r = reserve_workspace(e, pl, c.span, c.any_host))) return r;
     const int n = (int)c.jobs.size();
-    const size_t npx = (size_t)c.w * c.h;
+    const size_t npx = staged_image_bytes(c.w, c.h);  // staged images are 256-byte aligned
     long long stride = c.jobs[0].stride;
     if (c.any_host) {
         TW_HIP(e, hipMemcpyAsync(e->d_img, c.h_img, npx * 2 * n, hipMemcpyHostToDevice, st));
         stride = c.w;
     }
+    bool al4 = (stride % 4) == 0;
     for (int j = 0; j < n; j++) {
         const Job& jb = c.jobs[j];
         if (jb.h_a) {
@@ -753,7 +807,9 @@ tw_status flush_ctx(tw_engine* e, Ctx& c)
             c.h_ptrs[2 * j] = jb.d_a;
             c.h_ptrs[2 * j + 1] = jb.d_b;
         }
+        al4 = al4 && ((uintptr_t)c.h_ptrs[2 * j] % 4 == 0) && ((uintptr_t)c.h_ptrs[2 * j + 1] % 4 == 0);
     }
+    e->img_aligned4 = al4 ? 1 : 0;
     TW_HIP(e, hipMemcpyAsync((void*)e->d_ptrs, c.h_ptrs, sizeof(void*) * 2 * n, hipMemcpyHostToDevice, st));
     TW_HIP(e, hipEventRecord(c.ev_start, st));
     const int it = e->p.pyrIterations;
@@ -772,24 +828,34 @@ tw_status flush_ctx(tw_engine* e, Ctx& c)
                 launch_blur(e, st, L.w, L.h, L.ld, L.ps, e->M[i & 1], e->M[(i + 1) & 1], flow_cur, e->R, i < it - 1,
                             k, nc);
             if (k == 0 && c.span > 0) {
-                ScanArgs a;
-                a.flow = flow_cur;
-                a.fzs = 2 * L.ps;
-                a.fps = L.ps;
-                a.w = L.w;
-                a.h = L.h;
-                a.ld = L.ld;
-                a.span = c.span;
-                a.gw = (L.w + c.span - 1) / c.span;
-                a.gh = (L.h + c.span - 1) / c.span;
-                a.thr2 = c.threshold * c.threshold;
-                a.count = e->d_count + j0;
-                a.rec_zs = (long long)a.gw * a.gh;
-                a.rec = e->d_rec + (size_t)j0 * a.rec_zs;
+                // grid samples of this chunk -> dense per-pair buffer (the ordered scan runs once per batch)
+                GatherArgs g;
+                g.flow = flow_cur;
+                g.fzs = 2 * L.ps;
+                g.fps = L.ps;
+                g.ld = L.ld;
+                g.span = c.span;
+                g.gw = (L.w + c.span - 1) / c.span;
+                g.gh = (L.h + c.span - 1) / c.span;
+                g.g = e->d_grid + (size_t)j0 * g.gw * g.gh;
                 ProfScope pscope(e, st, TW_K_SCAN, 0);
-                hipLaunchKernelGGL(tw_span_scan, dim3(nc), dim3(1024), 0, st, a);
+                hipLaunchKernelGGL(tw_span_gather, dim3((g.gw + 63) / 64, (g.gh + 3) / 4, nc), dim3(256), 0, st, g);
             }
         }
+    }
+    if (c.span > 0) {
+        const LevelPlan& L = pl->lv[0];
+        ScanArgs a;
+        a.g = e->d_grid;
+        a.span = c.span;
+        a.gw = (L.w + c.span - 1) / c.span;
+        a.gh = (L.h + c.span - 1) / c.span;
+        a.thr2 = c.threshold * c.threshold;
+        a.count = e->d_count;
+        a.rec_zs = (long long)a.gw * a.gh;
+        a.rec = e->d_rec;
+        ProfScope pscope(e, st, TW_K_SCAN, 0);
+        hipLaunchKernelGGL(tw_span_scan, dim3(n), dim3(1024), 0, st, a);
     }
     TW_HIP(e, hipEventRecord(c.ev_stop, st));
     if (c.span > 0) {
@@ -804,6 +870,8 @@ tw_status flush_ctx(tw_engine* e, Ctx& c)
     c.launched = true;
     return TW_OK;
 }
+
+size_t staged_image_bytes(int w, int h) { return ((size_t)w * h + 255) / 256 * 256; }
 
 tw_status check_dims(tw_engine* e, int width, int height)
 {
@@ -854,7 +922,7 @@ tw_status submit_common(tw_engine* e, const uint8_t* h_a, const uint8_t* h_b, co
     Job jb;
     jb.stride = eff_stride;
     if (h_a) {
-        const size_t npx = (size_t)width * height;
+        const size_t npx = staged_image_bytes(width, height);
         const size_t need = npx * 2 * e->cap;
         if (need > c->h_img_cap) {
             // only ever happens on the first job of a batch (all jobs of a batch have one size)
@@ -972,6 +1040,7 @@ tw_status tw_engine_create(int device, const tw_params* params, int slots, tw_en
     window_kernel(p.winSize, e->wc);
     e->win_m = p.winSize / 2;
     if (const char* ev = getenv("TW_BLUR_VARIANT")) e->blur_variant = atoi(ev);
+    if (const char* ev = getenv("TW_PYR_GENERIC")) e->pyr_generic = atoi(ev);
     bool ok = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) == hipSuccess &&
               hipMalloc((void**)&e->d_ptrs, sizeof(void*) * 2 * slots + 256) == hipSuccess &&
               hipMalloc((void**)&e->d_count, sizeof(int) * slots + 256) == hipSuccess;
@@ -1006,6 +1075,7 @@ void tw_engine_destroy(tw_engine* e)
     if (e->d_ptrs) (void)hipFree((void*)e->d_ptrs);
     if (e->d_count) (void)hipFree(e->d_count);
     if (e->d_rec) (void)hipFree(e->d_rec);
+    if (e->d_grid) (void)hipFree(e->d_grid);
     for (Ctx& c : e->ctx) {
         if (c.h_img) (void)hipHostFree(c.h_img);
         if (c.h_ptrs) (void)hipHostFree((void*)c.h_ptrs);
@@ -1319,7 +1389,8 @@ extern "C" tw_status tw_bench_stage(tw_engine* e, int kclass, int width, int hei
     const size_t G = (size_t)tw_grid_capacity(width, height, span);
     int* cnt = t.alloc<int>(npairs);
     ScanRec* rec = t.alloc<ScanRec>(G * npairs);
-    if (!I || !R || !M0 || !M1 || !fl || !pf || !img || !tab || !cnt || !rec) return TW_E_NOMEM;
+    float2* grid = t.alloc<float2>(G * npairs);
+    if (!grid || !I || !R || !M0 || !M1 || !fl || !pf || !img || !tab || !cnt || !rec) return TW_E_NOMEM;
     {
         // deterministic pseudo-random fill (host LCG), smooth small flow
         std::vector<float> hb(ps * 10);
@@ -1365,7 +1436,10 @@ extern "C" tw_status tw_bench_stage(tw_engine* e, int kclass, int width, int hei
     for (int i = 0; i < TW_K_COUNT; i++) e->prof_level[i] = -2;
     auto once = [&](int i) -> tw_status {
         switch (kclass) {
-            case TW_K_PYR: launch_pyr(e, st, pl, level, tab, width, I, 2 * npairs); break;
+            case TW_K_PYR:
+                e->img_aligned4 = (npx0 % 4 == 0) ? 1 : 0;
+                launch_pyr(e, st, pl, level, tab, width, I, 2 * npairs);
+                break;
             case TW_K_POLYEXP: return launch_polyexp(e, st, L.w, L.h, L.ld, L.ps, I, R, 2 * npairs, level);
             case TW_K_UPDATE_MATRICES: launch_update(e, st, pl, level, R, fl, pf, M0, npairs); break;
             case TW_K_BLUR_SOLVE:
@@ -1373,9 +1447,12 @@ extern "C" tw_status tw_bench_stage(tw_engine* e, int kclass, int width, int hei
                             level, npairs);
                 break;
             case TW_K_SCAN: {
+                GatherArgs g;
+                g.flow = fl; g.fzs = 2 * L.ps; g.fps = L.ps; g.ld = L.ld; g.span = span;
+                g.gw = (L.w + span - 1) / span; g.gh = (L.h + span - 1) / span; g.g = grid;
+                hipLaunchKernelGGL(tw_span_gather, dim3((g.gw + 63) / 64, (g.gh + 3) / 4, npairs), dim3(256), 0, st, g);
                 ScanArgs a;
-                a.flow = fl; a.fzs = 2 * L.ps; a.fps = L.ps; a.w = L.w; a.h = L.h; a.ld = L.ld; a.span = span;
-                a.gw = (L.w + span - 1) / span; a.gh = (L.h + span - 1) / span; a.thr2 = 4.0; a.count = cnt;
+                a.g = grid; a.span = span; a.gw = g.gw; a.gh = g.gh; a.thr2 = 4.0; a.count = cnt;
                 a.rec = rec; a.rec_zs = (long long)a.gw * a.gh;
                 hipLaunchKernelGGL(tw_span_scan, dim3(npairs), dim3(1024), 0, st, a);
             } break;
@@ -1419,6 +1496,7 @@ tw_status tw_stage_pyr_level(tw_engine* e, const uint8_t* img, int w0, int h0, i
     const uint8_t* hp = d_img;
     TW_HIP(e, hipMemcpy((void*)d_tab, &hp, sizeof(hp), hipMemcpyHostToDevice));
     hipStream_t st = e->stream;
+    e->img_aligned4 = 1;  // hipMalloc'ed image, dense rows: the kernel itself checks stride % 4
     launch_pyr(e, st, pl, level, d_tab, w0, d_I, 1);
     TW_HIP(e, hipGetLastError());
     TW_HIP(e, hipStreamSynchronize(st));

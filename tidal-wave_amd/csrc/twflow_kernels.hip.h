@@ -190,6 +190,279 @@ __global__ __launch_bounds__(256) void tw_pyr_level(PyrArgs a)
     dst[(long long)oy * a.ld + ox] = out;
 }
 
+// -----------------------------------------------------------------------------------------------------
+// tw_pyr_level_lds : K1 with the u8 source region of the tile staged in LDS first (coalesced dword loads),
+//   so the (2r+1)-tap row filter reads bytes from LDS instead of issuing one global byte load per tap.
+//   Same tables, same arithmetic and order as tw_pyr_level.
+// -----------------------------------------------------------------------------------------------------
+struct PyrLdsArgs {
+    PyrArgs p;
+    int pitch_b;    // bytes per staged row (multiple of 4)
+    int aligned4;
+};
+
+__global__ __launch_bounds__(256) void tw_pyr_level_lds(PyrLdsArgs aa)
+{
+    const PyrArgs& a = aa.p;
+    extern __shared__ __attribute__((aligned(16))) float pyr_sm2[];
+    float* skern = pyr_sm2;                                   // [PYR_MAXK]
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * PYR_TW, y0 = blockIdx.y * PYR_TH;
+    const uint8_t* __restrict__ src = a.srcs[blockIdx.z];
+    float* __restrict__ dst = a.dst + blockIdx.z * a.dst_zs;
+    const int ksize = a.ksize, r = ksize >> 1;
+    const int P = (a.mode == 0) ? PYR_TW : 2 * PYR_TW;
+    const int yA = y0, yB = min(y0 + PYR_TH - 1, a.h - 1);
+    const int ylo = clampi(a.yofs[yA], 0, a.h0 - 1) - r;
+    const int yhi = clampi(a.yofs[yB] + 1, 0, a.h0 - 1) + r;
+    const int nrows = yhi - ylo + 1;
+    float* rowbuf = pyr_sm2 + PYR_MAXK;                               // [nrows_max][P]
+    unsigned* tile = (unsigned*)(rowbuf + (size_t)a.nrows_max * P);   // [nrows_max][pitch_b/4]
+    const uint8_t* tileb = (const uint8_t*)tile;
+    // source columns of the tile: positions 0 .. P-1
+    const int xl = min(x0, a.w - 1), xr = min(x0 + PYR_TW - 1, a.w - 1);
+    const int Xfirst = (a.mode == 0) ? xl : a.xofs[xl];
+    const int Xlast = (a.mode == 0) ? xr : a.xofs[xr] + 1;
+    const int xlo_a = (Xfirst - r) & ~3;  // floor to a multiple of 4 (also for negatives)
+    const int ndw = (Xlast + r - xlo_a) / 4 + 1;
+    const int pd = aa.pitch_b >> 2;
+
+    if (tid < ksize) skern[tid] = a.kern[tid];
+    int* xpos = (int*)(skern + PYR_MAXK - 64);  // source column of each of the P positions (ksize <= 63 here)
+    if (tid < P) {
+        const int oxp = min(x0 + ((a.mode == 0) ? tid : (tid >> 1)), a.w - 1);
+        xpos[tid] = (a.mode == 0) ? oxp : (a.xofs[oxp] + (tid & 1));
+    }
+    // ---- stage the u8 region: one dword per item, 8 items per thread in flight ----
+    {
+        const int total = nrows * ndw;
+        const float inv_ndw = 1.0f / (float)ndw;
+        // it / ndw without an integer divide (it < 2^20: the float estimate is off by at most one)
+        auto divmod = [&](int it, int& rr, int& dw) {
+            rr = (int)(((float)it + 0.5f) * inv_ndw);
+            dw = it - rr * ndw;
+            if (dw < 0) { rr--; dw += ndw; }
+            if (dw >= ndw) { rr++; dw -= ndw; }
+        };
+        for (int base = tid; base < total; base += 256 * 8) {
+            unsigned v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int it = base + u * 256;
+                v[u] = 0;
+                if (it < total) {
+                    int rr, dw;
+                    divmod(it, rr, dw);
+                    const int Y = reflect101(ylo + rr, a.h0);
+                    const uint8_t* __restrict__ S = src + (long long)Y * a.stride;
+                    const int c0 = xlo_a + 4 * dw;
+                    if (aa.aligned4 && c0 >= 0 && c0 + 3 < a.w0) {
+                        v[u] = *(const unsigned*)(S + c0);
+                    } else {
+                        v[u] = (unsigned)S[reflect101(c0, a.w0)] | ((unsigned)S[reflect101(c0 + 1, a.w0)] << 8) |
+                               ((unsigned)S[reflect101(c0 + 2, a.w0)] << 16) |
+                               ((unsigned)S[reflect101(c0 + 3, a.w0)] << 24);
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int it = base + u * 256;
+                if (it < total) {
+                    int rr, dw;
+                    divmod(it, rr, dw);
+                    tile[rr * pd + dw] = v[u];
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- row filter from LDS bytes ----
+    const float* kc = skern + r;
+    const int lgP = (a.mode == 0) ? 5 : 6;  // P = 32 or 64
+    const int p = tid & (P - 1);
+    const int X = xpos[p];
+    for (int rr = tid >> lgP; rr < nrows; rr += (256 >> lgP)) {
+        const uint8_t* T = tileb + rr * aa.pitch_b + (X - r - xlo_a);  // tap j at T[j]
+        float s;
+        if (ksize == 3) {
+            s = (float)T[1] * kc[0] + ((float)T[0] + (float)T[2]) * kc[1];
+        } else if (ksize == 5) {
+            s = (float)T[2] * kc[0] + ((float)T[1] + (float)T[3]) * kc[1] + ((float)T[0] + (float)T[4]) * kc[2];
+        } else if (ksize == 1) {
+            s = (float)T[0] * kc[0];
+        } else {
+            // left-to-right accumulation; taps are fetched 8 at a time so that the LDS reads of a group are
+            // in flight together (a tap-by-tap loop is bound by one LDS round trip per tap)
+            s = skern[0] * (float)T[0];
+            int j0 = 1;
+            for (; j0 + 8 <= ksize; j0 += 8) {
+                float t[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) t[u] = (float)T[j0 + u];
+#pragma unroll
+                for (int u = 0; u < 8; u++) s += skern[j0 + u] * t[u];
+            }
+            for (; j0 < ksize; j0++) s += skern[j0] * (float)T[j0];
+        }
+        rowbuf[rr * P + p] = s;
+    }
+    __syncthreads();
+
+    // ---- column filter at the sampled rows + resize combine (as tw_pyr_level) ----
+    const int tx = tid & (PYR_TW - 1), ty = tid / PYR_TW;
+    const int ox = x0 + tx, oy = y0 + ty;
+    if (ox >= a.w || oy >= a.h) return;
+    const int sy = a.yofs[oy];
+    const int s0 = clampi(sy, 0, a.h0 - 1) - ylo, s1 = clampi(sy + 1, 0, a.h0 - 1) - ylo;
+    auto colf = [&](int srow, int p) -> float {
+        const float* R = rowbuf + srow * P + p;
+        if (ksize == 3) return (R[-P] + R[P]) * kc[1] + R[0] * kc[0];
+        if (ksize == 1) return kc[0] * R[0];
+        float s = kc[0] * R[0];
+        int j = 1;
+        for (; j + 4 <= r + 1; j += 4) {
+            float up[4], dn[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                up[u] = R[(j + u) * P];
+                dn[u] = R[-(j + u) * P];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) s += kc[j + u] * (up[u] + dn[u]);
+        }
+        for (; j <= r; j++) s += kc[j] * (R[j * P] + R[-j * P]);
+        return s;
+    };
+    float out;
+    if (a.mode == 0) {
+        out = colf(s0, tx);
+    } else if (a.mode == 2) {
+        float sum = 0.f;
+        sum += colf(s0, 2 * tx) + colf(s0, 2 * tx + 1) + colf(s1, 2 * tx) + colf(s1, 2 * tx + 1);
+        out = sum * 0.25f;
+    } else {
+        float t0, t1;
+        if (ox < a.xmax) {
+            const float a0 = a.alpha[2 * ox], a1 = a.alpha[2 * ox + 1];
+            t0 = colf(s0, 2 * tx) * a0 + colf(s0, 2 * tx + 1) * a1;
+            t1 = colf(s1, 2 * tx) * a0 + colf(s1, 2 * tx + 1) * a1;
+        } else {
+            t0 = colf(s0, 2 * tx) * 1.f;
+            t1 = colf(s1, 2 * tx) * 1.f;
+        }
+        out = t0 * a.beta[2 * oy] + t1 * a.beta[2 * oy + 1];
+    }
+    dst[(long long)oy * a.ld + ox] = out;
+}
+
+// -----------------------------------------------------------------------------------------------------
+// tw_pyr_k3<MODE> : register-only fast path of K1 for 3-tap smoothing (the two finest levels of a
+//   pyr_scale = 0.5 pyramid: MODE 0 = level 0, same size; MODE 2 = level 1, exact 2x2 area-fast resize).
+//   A thread reads whole dwords of the u8 rows (coalesced), converts with v_cvt_f32_ubyteN and produces
+//   4 x 2 (MODE 0) or 4 x 1 (MODE 2) output pixels, stored as 16-byte vectors.  Same float operation order
+//   as the generic kernel: row filter S0*k0 + (S-1 + S+1)*k1, column filter (R-1 + R+1)*k1 + R0*k0.
+// -----------------------------------------------------------------------------------------------------
+struct PyrK3Args {
+    const uint8_t* const* srcs;
+    float* dst;
+    long long dst_zs;
+    long long stride;
+    int w0, h0, w, h, ld;
+    float k0, k1;  // centre / side tap
+    int aligned4;  // rows start 4-byte aligned: whole-dword loads allowed
+};
+
+// v[j] = (float)S[reflect101(xs + j)], j = 0..NV-1, where xs = 4*m - 1 (so xs+1 is dword aligned)
+template <int NV>
+__device__ __forceinline__ void pyr_load_row(const uint8_t* __restrict__ S, int xs, int w0, bool fast, float* v)
+{
+    if (fast) {
+        // dwords at xs-3, xs+1, xs+5, ... : last byte of the first, all of the middle ones, first of the last
+        const unsigned* D = (const unsigned*)(S + xs - 3);
+        constexpr int ND = (NV + 2) / 4 + 1;
+        unsigned d[ND];
+#pragma unroll
+        for (int i = 0; i < ND; i++) d[i] = D[i];
+#pragma unroll
+        for (int j = 0; j < NV; j++) {
+            const int b = j + 3;  // byte index from xs-3
+            v[j] = (float)((d[b >> 2] >> (8 * (b & 3))) & 0xffu);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < NV; j++) v[j] = (float)S[reflect101(xs + j, w0)];
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void tw_pyr_k3(PyrK3Args a)
+{
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int ox = (blockIdx.x * 64 + tx) * 4;
+    const uint8_t* __restrict__ src = a.srcs[blockIdx.z];
+    float* __restrict__ dst = a.dst + blockIdx.z * a.dst_zs;
+    if (ox >= a.w) return;
+    const float k0 = a.k0, k1 = a.k1;
+    if (MODE == 0) {
+        const int oy = (blockIdx.y * 4 + ty) * 2;
+        if (oy >= a.h) return;
+        const bool fast = a.aligned4 && ox >= 4 && ox + 8 <= a.w0;
+        float rf[4][4];
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++) {
+            const int Y = reflect101(oy - 1 + rr, a.h0);
+            float v[6];
+            pyr_load_row<6>(src + (long long)Y * a.stride, ox - 1, a.w0, fast, v);
+#pragma unroll
+            for (int j = 0; j < 4; j++) rf[rr][j] = v[j + 1] * k0 + (v[j] + v[j + 2]) * k1;
+        }
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            if (oy + q >= a.h) break;
+            float o[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) o[j] = (rf[q][j] + rf[q + 2][j]) * k1 + rf[q + 1][j] * k0;
+            float* d = dst + (long long)(oy + q) * a.ld + ox;
+            if (ox + 3 < a.w) *(f32x4*)d = f32x4{o[0], o[1], o[2], o[3]};
+            else
+                for (int j = 0; j < 4; j++)
+                    if (ox + j < a.w) d[j] = o[j];
+        }
+    } else {
+        const int oy = blockIdx.y * 4 + ty;
+        if (oy >= a.h) return;
+        const int sx = 2 * ox;  // first source column of the 8 blurred samples
+        const bool fast = a.aligned4 && sx >= 4 && sx + 12 <= a.w0;
+        float rf[4][8];
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++) {
+            const int Y = reflect101(2 * oy - 1 + rr, a.h0);
+            float v[10];
+            pyr_load_row<10>(src + (long long)Y * a.stride, sx - 1, a.w0, fast, v);
+#pragma unroll
+            for (int j = 0; j < 8; j++) rf[rr][j] = v[j + 1] * k0 + (v[j] + v[j + 2]) * k1;
+        }
+        float o[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const float b00 = (rf[0][2 * i] + rf[2][2 * i]) * k1 + rf[1][2 * i] * k0;
+            const float b01 = (rf[0][2 * i + 1] + rf[2][2 * i + 1]) * k1 + rf[1][2 * i + 1] * k0;
+            const float b10 = (rf[1][2 * i] + rf[3][2 * i]) * k1 + rf[2][2 * i] * k0;
+            const float b11 = (rf[1][2 * i + 1] + rf[3][2 * i + 1]) * k1 + rf[2][2 * i + 1] * k0;
+            float sum = 0.f;
+            sum += b00 + b01 + b10 + b11;
+            o[i] = sum * 0.25f;
+        }
+        float* d = dst + (long long)oy * a.ld + ox;
+        if (ox + 3 < a.w) *(f32x4*)d = f32x4{o[0], o[1], o[2], o[3]};
+        else
+            for (int j = 0; j < 4; j++)
+                if (ox + j < a.w) d[j] = o[j];
+    }
+}
+
 // =====================================================================================================
 // K5  tw_polyexp<N> : FarnebackPolyExp (optflowgf.cpp) — the roofline-graded kernel, 24 B/px algorithmic.
 //   Tile = 240 columns x 8 rows per 256-thread workgroup (240 + 2x8 halo columns = 256 = one column per
@@ -1005,21 +1278,40 @@ __global__ __launch_bounds__(256) void tw_blur_solve_generic(BlurArgs a)
 }
 
 // =====================================================================================================
-// K12  tw_span_scan : the span-grid threshold scan of /root/reference/src/consumer.cpp:60-76.
-//   len = dx*dx + dy*dy in float, compared in double against threshold*threshold (strict >);
-//   flagged grid vectors are compacted in the reference's row-major order (y, then x) so that only the
-//   hits cross PCIe.  One 1024-thread workgroup per image pair (blockIdx.x); grid points are visited
-//   1024 at a time (lane-consecutive points), order is restored with wave ballots + one LDS scan of the
-//   per-wave counts per round of 32 x 1024 points.
+// K12  the span-grid threshold scan of /root/reference/src/consumer.cpp:60-76, in two kernels:
+//   tw_span_gather : one thread per grid point copies (dx,dy) at (x*span, y*span) into a dense per-pair
+//                    buffer — fully parallel, launched per level-0 chunk while the flow is still in cache;
+//   tw_span_scan   : one 1024-thread workgroup per pair (launched once per batch): len = dx*dx + dy*dy in
+//                    float, compared in double against threshold*threshold (strict >), hits compacted in the
+//                    reference's row-major order (y, then x) with wave ballots + one LDS scan of the per-wave
+//                    counts per round of 32 x 1024 points, so that only the hits cross PCIe.
 // =====================================================================================================
 struct ScanRec {
     int x, y;
     float dx, dy;
 };
-struct ScanArgs {
+struct GatherArgs {
     const float* flow;  // pair z: 2 planes at flow + z*fzs
     long long fzs, fps;
-    int w, h, ld;
+    int ld, span, gw, gh;
+    float2* g;  // pair z: gw*gh points at g + z*G
+};
+
+__global__ __launch_bounds__(256) void tw_span_gather(GatherArgs a)
+{
+    const int gx = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int gy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (gx >= a.gw || gy >= a.gh) return;
+    const float* __restrict__ fxp = a.flow + (long long)blockIdx.z * a.fzs;
+    const long long o = (long long)(gy * a.span) * a.ld + gx * a.span;
+    float2 v;
+    v.x = fxp[o];
+    v.y = fxp[o + a.fps];
+    a.g[(long long)blockIdx.z * a.gw * a.gh + gy * a.gw + gx] = v;
+}
+
+struct ScanArgs {
+    const float2* g;  // pair z: dense grid samples at g + z*G
     int span, gw, gh;
     double thr2;
     int* count;    // [pairs]
@@ -1035,27 +1327,33 @@ __global__ __launch_bounds__(1024) void tw_span_scan(ScanArgs a)
     __shared__ int round_total;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int z = blockIdx.x;
-    const float* __restrict__ fxp = a.flow + (long long)z * a.fzs;
-    const float* __restrict__ fyp = fxp + a.fps;
-    ScanRec* __restrict__ rec = a.rec + (long long)z * a.rec_zs;
     const int G = a.gw * a.gh;
+    const float2* __restrict__ g = a.g + (long long)z * G;
+    ScanRec* __restrict__ rec = a.rec + (long long)z * a.rec_zs;
     int base_out = 0;
     for (int base = 0; base < G; base += SCAN_IT * 1024) {
         const int nit = min(SCAN_IT, (G - base + 1023) / 1024);
         unsigned mask = 0;
-        for (int i = 0; i < nit; i++) {
-            const int idx = base + i * 1024 + tid;
-            bool f = false;
-            if (idx < G) {
-                const int gy = idx / a.gw, gx = idx - gy * a.gw;
-                const long long o = (long long)(gy * a.span) * a.ld + gx * a.span;
-                const float dx = fxp[o], dy = fyp[o];
-                const float len = (dx * dx) + (dy * dy);
-                f = (double)len > a.thr2;
+        for (int i0 = 0; i0 < nit; i0 += 8) {
+            float2 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int idx = base + (i0 + u) * 1024 + tid;
+                v[u] = float2{0.f, 0.f};
+                if (i0 + u < nit && idx < G) v[u] = g[idx];
             }
-            const unsigned long long b = __ballot(f);
-            if (lane == 0) wsum[i * 16 + wave] = __popcll(b);
-            mask |= f ? (1u << i) : 0u;
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int i = i0 + u;
+                if (i < nit) {  // wave-uniform
+                    const int idx = base + i * 1024 + tid;
+                    const float len = (v[u].x * v[u].x) + (v[u].y * v[u].y);
+                    const bool f = idx < G && (double)len > a.thr2;
+                    const unsigned long long b = __ballot(f);
+                    if (lane == 0) wsum[i * 16 + wave] = __popcll(b);
+                    mask |= f ? (1u << i) : 0u;
+                }
+            }
         }
         __syncthreads();
         // exclusive scan of the nit*16 per-wave counts (<= 512 entries) in place
@@ -1078,13 +1376,13 @@ __global__ __launch_bounds__(1024) void tw_span_scan(ScanArgs a)
             if (f) {
                 const int idx = base + i * 1024 + tid;
                 const int gy = idx / a.gw, gx = idx - gy * a.gw;
-                const long long o = (long long)(gy * a.span) * a.ld + gx * a.span;
                 const int pos = base_out + wsum[i * 16 + wave] + __popcll(b & ((1ull << lane) - 1ull));
+                const float2 vv = g[idx];
                 ScanRec rr;
                 rr.x = gx * a.span;
                 rr.y = gy * a.span;
-                rr.dx = fxp[o];
-                rr.dy = fyp[o];
+                rr.dx = vv.x;
+                rr.dy = vv.y;
                 rec[pos] = rr;
             }
         }
