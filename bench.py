@@ -147,10 +147,9 @@ def main():
         step()
     barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    import shard
+    elapsed, (flagged_total, pairs_total) = shard.reduce_max_sum(
+        dist, torch.device("cuda", local_rank), elapsed, [flagged[0], args.batch * args.steps])
 
     prof = {}
     if not args.no_prof:
@@ -160,7 +159,6 @@ def main():
         eng.prof_select(-1, -2)
 
     if rank == 0:
-        pairs_total = args.batch * args.steps * world
         value = pairs_total / elapsed
         bytes_pair = eng.algorithmic_bytes_pair(W, H, SPAN)
         traffic = {}
@@ -203,7 +201,7 @@ def main():
                               "frac_of_8TBps": round(bytes_pair * value / world / 1e9 / HBM_PEAK_GBS, 4)},
             "roofline": roof(twflow.K_BLUR_SOLVE),
             "roofline_polyexp": roof(twflow.K_POLYEXP),
-            "flagged_vectors": flagged[0],
+            "flagged_vectors": flagged_total,
         }
         if world == 1 and not args.no_cpu_baseline:
             cb, cpu_out = cpu_baseline(host_pairs)

@@ -1,0 +1,75 @@
+"""The Node.js surface (N-API addon + index.js): argument checks, event payloads, decode — and, on a GPU,
+the reference's own four mocha cases (test/index.coffee) restated in plain node."""
+import json
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "tidal-wave_amd", "host")
+ADDON = os.path.join(HOST, "build", "Release", "tidalwave.node")
+
+needs_node = pytest.mark.skipif(shutil.which("node") is None or not os.path.exists(ADDON),
+                                reason="node or the built addon is not available")
+
+
+def node(script, *args, timeout=120):
+    return subprocess.run(["node", "-e", script, *args], cwd=HOST, capture_output=True, text=True, timeout=timeout)
+
+
+@needs_node
+def test_calc_argument_checks_and_error_event():
+    # src/broker.cpp:127-139 TypeErrors; src/opticalflow.cpp:40 reason text; report counters
+    r = node("""
+var T=require('./index'); var t=new T.TidalWave({span:'10', threshold:3}); var out=[];
+[function(){t.calc('a')}, function(){t.calc(1,'b')}, function(){t.calc('a',2)}].forEach(function(f){
+  try{f()}catch(e){out.push(e.name+': '+e.message)}});
+t.on('error',function(e){out.push(e); t.dispose();});
+t.on('finish',function(r){out.push(r); console.log(JSON.stringify(out));});
+t.calc('/nonexistent/a.png','/nonexistent/b.png');
+""")
+    assert r.returncode == 0, r.stderr
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out[:3] == ["TypeError: 2 arguments expected", "TypeError: Wrong arguments(expect_image)",
+                       "TypeError: Wrong arguments(target_image)"]
+    assert out[3] == {"status": "ERROR", "reason": "Can't open /nonexistent/a.png"}
+    assert out[4] == {"request": 1, "data": 0, "error": 1}
+
+
+@needs_node
+def test_missing_target_dir_finishes_with_zero_report():
+    # test/index.coffee:98-104 — runs without a GPU (no job is ever created)
+    r = subprocess.run(["node", "test_reference.js", "nogpu"], cwd=HOST, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
+@needs_node
+def test_png_decode_matches_golden_gray(tmp_path):
+    """Host PNG decode (zlib inflate + unfilter + libpng-1.5 gray) == the committed .pgm decodes."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as O
+    for rev in ("expected", "revision1", "revision2"):
+        png = os.path.join(ROOT, "tests", "golden", "tree", rev, "scenario2", "capture2.png")
+        out = tmp_path / (rev + ".bin")
+        r = node("var a=require('./build/Release/tidalwave'); var d=a.decodeGray(process.argv[1]);"
+                 "require('fs').writeFileSync(process.argv[2], d.data); console.log(d.width+' '+d.height)",
+                 png, str(out))
+        assert r.returncode == 0, r.stderr
+        w, h = map(int, r.stdout.split())
+        got = np.fromfile(out, np.uint8).reshape(h, w)
+        want = O.read_pgm(os.path.join(ROOT, "tests", "golden", "%s_scenario2_capture2.pgm" % rev))
+        assert np.array_equal(got, want)
+
+
+@needs_node
+@pytest.mark.gpu
+def test_reference_mocha_suite_in_node():
+    """All four cases of test/index.coffee through create() -> addon -> libtwflow.so on the GPU, including the
+    24 golden vectors with exact dx/dy and the payload key order of src/broker.cpp:165-185."""
+    r = subprocess.run(["node", "test_reference.js"], cwd=HOST, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "all 4 reference tests passed" in r.stdout

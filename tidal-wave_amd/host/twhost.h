@@ -1,0 +1,155 @@
+// twhost.h — C++ host layer above the C ABI: the job queue, the per-GPU consumers and the result pump of
+// tidal-wave (reference: src/message_queue.h, src/consumer.{h,cpp}, src/manager.{h,cpp}), re-stated on
+// std::thread / std::mutex instead of libuv primitives.  Everything device-side goes through include/twflow.h.
+#pragma once
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/twflow.h"
+
+namespace twhost {
+
+// /root/reference/src/message_queue.h:13-48
+struct Request {
+    std::string expect_image;
+    std::string target_image;
+    double threshold;
+    int span;
+};
+struct Vector {
+    int x, y;
+    double dx, dy;
+};
+struct Response {
+    std::vector<Vector> vectors;
+    std::string expect_image, target_image;
+    float time = 0;
+    double threshold = 0;
+    int span = 0;
+    std::string status, reason;
+    int width = 0, height = 0;
+};
+struct Report {
+    int requestCount = 0, dataCount = 0, errorCount = 0;
+};
+
+// struct Parameter of the reference (src/manager.h): per-instance options resolved by the broker
+struct Parameter {
+    double threshold = 5.0;
+    int span = 10;
+    int numThreads = 4;
+    tw_params optParam;
+};
+
+// Blocking MPMC queue, MessageQueue<T> of src/message_queue.h:50-118 (stop() wakes every waiter; as in the
+// reference, items still queued at stop() are dropped — Appendix B#8 of SURVEY.md).
+template <typename T>
+class MessageQueue {
+public:
+    bool tryPop(T& out)
+    {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [&] { return !q_.empty() || !running_; });
+        if (q_.empty() || !running_) return false;
+        out = std::move(q_.front());
+        q_.pop_front();
+        return true;
+    }
+    // non-blocking: used by a consumer to fill a GPU batch with whatever is already queued
+    bool tryPopNow(T& out)
+    {
+        std::lock_guard<std::mutex> lk(m_);
+        if (q_.empty() || !running_) return false;
+        out = std::move(q_.front());
+        q_.pop_front();
+        return true;
+    }
+    void push(T v)
+    {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            q_.push_back(std::move(v));
+        }
+        cv_.notify_one();
+    }
+    void stop()
+    {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            running_ = false;
+        }
+        cv_.notify_all();
+    }
+
+private:
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::deque<T> q_;
+    bool running_ = true;
+};
+
+// 8-bit gray decode of a file: PGM (P5) and PNG (zlib inflate + unfilter, libpng-1.5 gray conversion).
+// Returns false if the file cannot be opened / decoded ("Can't open <path>", src/opticalflow.cpp:40,47).
+bool load_gray(const std::string& path, std::vector<uint8_t>& img, int& w, int& h);
+// cv::resize(8-bit, INTER_LINEAR) — the "<= 5 px" reconcile of src/opticalflow.cpp:64-68.
+void resize_u8_linear(const std::vector<uint8_t>& src, int sw, int sh, std::vector<uint8_t>& dst, int dw, int dh);
+
+// Observer of src/observer.h:11-18
+struct Observer {
+    std::function<void(const Response&)> onNext;
+    std::function<void(const std::string&)> onError;
+    std::function<void(const Report&)> onCompleted;
+};
+
+// Consumer (src/consumer.{h,cpp}): one worker thread bound to one GPU; pulls requests, runs the engine, pushes
+// responses.  Consumer i uses device i % deviceCount; with no HIP device every job answers ERROR (the engine
+// has no CPU path).
+class Consumer {
+public:
+    Consumer(int id, MessageQueue<Request>& req, MessageQueue<Response>& res, const tw_params& p, int batch);
+    ~Consumer();
+    void start();
+    void join();
+
+private:
+    void run();
+    int id_;
+    MessageQueue<Request>& req_;
+    MessageQueue<Response>& res_;
+    tw_params params_;
+    int batch_;
+    std::thread th_;
+};
+
+// Manager (src/manager.{h,cpp}): owns the queues and the consumers; a pump thread hands responses to the
+// observer (the addon forwards them to the JS thread).
+class Manager {
+public:
+    explicit Manager(Observer obs) : obs_(std::move(obs)) {}
+    ~Manager();
+    void start(const Parameter& p);
+    int request(const std::string& expect_image, const std::string& target_image);
+    void stop();  // idempotent; completion is reported through onCompleted
+    bool running() const { return running_; }
+
+private:
+    void work();
+    Observer obs_;
+    Parameter param_;
+    MessageQueue<Request> requestQueue_;
+    MessageQueue<Response> responseQueue_;
+    std::vector<Consumer*> consumers_;
+    std::thread pump_;
+    std::atomic<bool> running_{false};
+    std::atomic<bool> stopped_{false};
+    Report report_;
+    std::mutex report_m_;
+};
+
+}  // namespace twhost
