@@ -279,6 +279,12 @@ struct tw_engine {
     WinCoef wc;
     int win_m = 15;
     int img_aligned4 = 0;  // every image pointer and the row stride of the batch being enqueued are 4-byte aligned
+    int lanes = 1;         // TW_LANES=2: the two halves of a batch run on two streams (memory-bound kernels of one
+                           // half overlap the VALU-bound blur of the other); per-kernel hipEvent durations then
+                           // include the co-running kernel
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int blur_tps = 4;      // tiles per strip of the wave-specialised kernel (TW_BLUR_TPS)
     int pyr_generic = 0;   // TW_PYR_GENERIC=1: always the generic pyramid kernel (A/B, parity cross-check)
     int blur_variant = 6;  // 6: v4 structure, refresh fused into the solve phase (default); 7: v4 + separate refresh; 0-5, 8-10: earlier structures / ILP sweeps kept for A/B
     std::string err;
@@ -466,10 +472,11 @@ tw_status reserve_workspace(tw_engine* e, const Plan* pl, int span, bool need_im
 {
     size_t need = 0;
     for (const LevelPlan& L : pl->lv) need = std::max(need, (size_t)L.ps * 2 * L.chunk);
+    need *= e->lanes;  // one workspace per lane, carved from the same allocations
     bool grow = need > e->ws_elems || e->flow.size() < pl->lv.size();
     if (!grow)
         for (size_t k = 0; k < pl->lv.size(); k++) {
-            const size_t fc = (size_t)pl->lv[k].ps * 2 * (k == 0 ? pl->lv[0].chunk : e->cap);
+            const size_t fc = (size_t)pl->lv[k].ps * 2 * (k == 0 ? pl->lv[0].chunk * e->lanes : e->cap);
             if (fc > e->flow_cap[k]) grow = true;
         }
     const size_t img = staged_image_bytes(pl->w0, pl->h0) * 2 * e->cap;
@@ -478,6 +485,7 @@ tw_status reserve_workspace(tw_engine* e, const Plan* pl, int span, bool need_im
     if (G * e->cap > e->d_rec_cap) grow = true;
     if (!grow) return TW_OK;
     TW_HIP(e, hipStreamSynchronize(e->stream));
+    TW_HIP(e, hipStreamSynchronize(e->stream2));
     if (need > e->ws_elems) {
         if (e->I) (void)hipFree(e->I);
         if (e->R) (void)hipFree(e->R);
@@ -496,7 +504,7 @@ tw_status reserve_workspace(tw_engine* e, const Plan* pl, int span, bool need_im
         e->flow_cap.resize(pl->lv.size(), 0);
     }
     for (size_t k = 0; k < pl->lv.size(); k++) {
-        const size_t fc = (size_t)pl->lv[k].ps * 2 * (k == 0 ? pl->lv[0].chunk : e->cap);
+        const size_t fc = (size_t)pl->lv[k].ps * 2 * (k == 0 ? pl->lv[0].chunk * e->lanes : e->cap);
         if (fc > e->flow_cap[k]) {
             if (e->flow[k]) (void)hipFree(e->flow[k]);
             e->flow[k] = nullptr;
@@ -685,7 +693,20 @@ void launch_blur(tw_engine* e, hipStream_t st, int w, int h, int ld, long long p
     bool fused = true;
     {
         ProfScope pscope(e, st, TW_K_BLUR_SOLVE, level);
-        if (e->win_m == 15 && e->blur_variant >= 8 && e->blur_variant <= 10) {
+        if (e->win_m == 15 && e->blur_variant == 11 && update) {
+            // v5: wave-specialised fused kernel for refreshing iterations (the last iteration uses v4)
+            const int tps = e->blur_tps;
+            if (wide) {
+                const int tiles = ((w + 223) / 224) * gy;
+                hipLaunchKernelGGL((tw_blur_solve5<15, 256, 16, 8>), dim3(((tiles + tps - 1) / tps) * npairs), dim3(512), 0, st, a, tps);
+            } else {
+                const int tiles = ((w + 95) / 96) * gy;
+                hipLaunchKernelGGL((tw_blur_solve5<15, 128, 16, 8>), dim3(((tiles + tps - 1) / tps) * npairs), dim3(256), 0, st, a, tps);
+            }
+        } else if (e->win_m == 15 && e->blur_variant == 11) {
+            if (wide) hipLaunchKernelGGL((tw_blur_solve4<15, 256, 16, 8, true>), dim3((w + 223) / 224, gy, npairs), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((tw_blur_solve4<15, 128, 16, 8, true>), dim3((w + 95) / 96, gy, npairs), dim3(128), 0, st, a);
+        } else if (e->win_m == 15 && e->blur_variant >= 8 && e->blur_variant <= 10) {
             // ILP sweeps of the v4 structure (fused refresh)
             if (e->blur_variant == 8) {
                 if (wide) hipLaunchKernelGGL((tw_blur_solve4<15, 256, 16, 8, true, 4, 4>), dim3((w + 223) / 224, gy, npairs), dim3(256), 0, st, a);
@@ -813,35 +834,54 @@ tw_status flush_ctx(tw_engine* e, Ctx& c)
     TW_HIP(e, hipMemcpyAsync((void*)e->d_ptrs, c.h_ptrs, sizeof(void*) * 2 * n, hipMemcpyHostToDevice, st));
     TW_HIP(e, hipEventRecord(c.ev_start, st));
     const int it = e->p.pyrIterations;
-    for (int k = pl->levels; k >= 0; k--) {
-        const LevelPlan& L = pl->lv[k];
-        for (int j0 = 0; j0 < n; j0 += L.chunk) {
-            const int nc = std::min(L.chunk, n - j0);
-            // flow buffers: levels >= 1 keep every pair of the batch, level 0 only the current chunk
-            float* flow_cur = e->flow[k] + (k == 0 ? 0 : (size_t)j0 * 2 * L.ps);
-            const float* flow_prev =
-                k < pl->levels ? e->flow[k + 1] + (size_t)j0 * 2 * pl->lv[k + 1].ps : nullptr;
-            launch_pyr(e, st, pl, k, e->d_ptrs + 2 * j0, stride, e->I, 2 * nc);
-            if ((r = launch_polyexp(e, st, L.w, L.h, L.ld, L.ps, e->I, e->R, 2 * nc, k))) return r;
-            launch_update(e, st, pl, k, e->R, flow_cur, flow_prev, e->M[0], nc);
-            for (int i = 0; i < it; i++)
-                launch_blur(e, st, L.w, L.h, L.ld, L.ps, e->M[i & 1], e->M[(i + 1) & 1], flow_cur, e->R, i < it - 1,
-                            k, nc);
-            if (k == 0 && c.span > 0) {
-                // grid samples of this chunk -> dense per-pair buffer (the ordered scan runs once per batch)
-                GatherArgs g;
-                g.flow = flow_cur;
-                g.fzs = 2 * L.ps;
-                g.fps = L.ps;
-                g.ld = L.ld;
-                g.span = c.span;
-                g.gw = (L.w + c.span - 1) / c.span;
-                g.gh = (L.h + c.span - 1) / c.span;
-                g.g = e->d_grid + (size_t)j0 * g.gw * g.gh;
-                ProfScope pscope(e, st, TW_K_SCAN, 0);
-                hipLaunchKernelGGL(tw_span_gather, dim3((g.gw + 63) / 64, (g.gh + 3) / 4, nc), dim3(256), 0, st, g);
+    const int nlanes = (e->lanes > 1 && n >= 2) ? e->lanes : 1;
+    if (nlanes > 1) {
+        TW_HIP(e, hipEventRecord(e->ev_fork, st));  // uploads + whatever ran before on the main stream
+        TW_HIP(e, hipStreamWaitEvent(e->stream2, e->ev_fork, 0));
+    }
+    size_t ws_lane = 0;
+    for (const LevelPlan& L : pl->lv) ws_lane = std::max(ws_lane, (size_t)L.ps * 2 * L.chunk);
+    for (int lane = 0; lane < nlanes; lane++) {
+        hipStream_t ls = lane == 0 ? st : e->stream2;
+        const int lo = (int)((long long)n * lane / nlanes), hi = (int)((long long)n * (lane + 1) / nlanes);
+        float* I = e->I + ws_lane * lane;
+        float* R = e->R + ws_lane * 5 * lane;
+        float* M0 = e->M[0] + ws_lane / 2 * 5 * lane;
+        float* M1 = e->M[1] + ws_lane / 2 * 5 * lane;
+        for (int k = pl->levels; k >= 0; k--) {
+            const LevelPlan& L = pl->lv[k];
+            for (int j0 = lo; j0 < hi; j0 += L.chunk) {
+                const int nc = std::min(L.chunk, hi - j0);
+                // flow buffers: levels >= 1 keep every pair of the batch, level 0 only the lane's current chunk
+                float* flow_cur = e->flow[k] + (k == 0 ? (size_t)lane * L.chunk * 2 * L.ps : (size_t)j0 * 2 * L.ps);
+                const float* flow_prev =
+                    k < pl->levels ? e->flow[k + 1] + (size_t)j0 * 2 * pl->lv[k + 1].ps : nullptr;
+                launch_pyr(e, ls, pl, k, e->d_ptrs + 2 * j0, stride, I, 2 * nc);
+                if ((r = launch_polyexp(e, ls, L.w, L.h, L.ld, L.ps, I, R, 2 * nc, k))) return r;
+                launch_update(e, ls, pl, k, R, flow_cur, flow_prev, M0, nc);
+                for (int i = 0; i < it; i++)
+                    launch_blur(e, ls, L.w, L.h, L.ld, L.ps, (i & 1) ? M1 : M0, (i & 1) ? M0 : M1, flow_cur, R,
+                                i < it - 1, k, nc);
+                if (k == 0 && c.span > 0) {
+                    // grid samples of this chunk -> dense per-pair buffer (the ordered scan runs once per batch)
+                    GatherArgs g;
+                    g.flow = flow_cur;
+                    g.fzs = 2 * L.ps;
+                    g.fps = L.ps;
+                    g.ld = L.ld;
+                    g.span = c.span;
+                    g.gw = (L.w + c.span - 1) / c.span;
+                    g.gh = (L.h + c.span - 1) / c.span;
+                    g.g = e->d_grid + (size_t)j0 * g.gw * g.gh;
+                    ProfScope pscope(e, ls, TW_K_SCAN, 0);
+                    hipLaunchKernelGGL(tw_span_gather, dim3((g.gw + 63) / 64, (g.gh + 3) / 4, nc), dim3(256), 0, ls, g);
+                }
             }
         }
+    }
+    if (nlanes > 1) {
+        TW_HIP(e, hipEventRecord(e->ev_join, e->stream2));
+        TW_HIP(e, hipStreamWaitEvent(st, e->ev_join, 0));
     }
     if (c.span > 0) {
         const LevelPlan& L = pl->lv[0];
@@ -1041,7 +1081,12 @@ tw_status tw_engine_create(int device, const tw_params* params, int slots, tw_en
     e->win_m = p.winSize / 2;
     if (const char* ev = getenv("TW_BLUR_VARIANT")) e->blur_variant = atoi(ev);
     if (const char* ev = getenv("TW_PYR_GENERIC")) e->pyr_generic = atoi(ev);
+    if (const char* ev = getenv("TW_BLUR_TPS")) e->blur_tps = std::max(1, atoi(ev));
+    if (const char* ev = getenv("TW_LANES")) e->lanes = std::min(2, std::max(1, atoi(ev)));
     bool ok = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking) == hipSuccess &&
+              hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) == hipSuccess &&
               hipMalloc((void**)&e->d_ptrs, sizeof(void*) * 2 * slots + 256) == hipSuccess &&
               hipMalloc((void**)&e->d_count, sizeof(int) * slots + 256) == hipSuccess;
     for (Ctx& c : e->ctx) {
@@ -1086,6 +1131,9 @@ void tw_engine_destroy(tw_engine* e)
         if (c.ev_done) (void)hipEventDestroy(c.ev_done);
     }
     if (e->stream) (void)hipStreamDestroy(e->stream);
+    if (e->stream2) (void)hipStreamDestroy(e->stream2);
+    if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+    if (e->ev_join) (void)hipEventDestroy(e->ev_join);
     for (auto& kv : e->plans) free_plan(kv.second);
     for (auto& pend : e->prof_pending)
         for (ProfPair& pp : pend) {

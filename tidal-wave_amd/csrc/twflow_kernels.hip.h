@@ -1222,6 +1222,183 @@ __global__ __launch_bounds__(COLS) void tw_blur_solve4(BlurArgs a)
     }
 }
 
+// -----------------------------------------------------------------------------------------------------
+// tw_blur_solve5<MH,COLS,HALO,TH> : wave-specialised fused kernel for the iterations that refresh M.
+//   The blur of a tile is VALU-bound, the solve + UpdateMatrices refresh of a tile is HBM/gather-bound; run one
+//   after the other they add up (v4).  Here a 2*COLS-thread workgroup walks a strip of tiles with two roles:
+//     waves 0..COLS/64-1  ("blur")    : vertical + horizontal window average of tile t   -> LDS buffer t&1
+//     waves COLS/64..     ("refresh") : 2x2 solve, flow store and M refresh of tile t-1  <- LDS buffer (t-1)&1
+//   so the memory-bound half of tile t-1 overlaps the compute-bound half of tile t on the same CU.  Both roles
+//   meet at the three workgroup barriers of a step (gfx950 has no named barriers); the refresh role splits its
+//   pixels 4 : 3 over the first two segments.  Arithmetic and order are those of v4 (bit-identical results).
+// -----------------------------------------------------------------------------------------------------
+template <int MH, int COLS, int HALO, int TH>
+__global__ __launch_bounds__(2 * COLS) void tw_blur_solve5(BlurArgs a, int tps /*tiles per strip*/)
+{
+    constexpr int TW = COLS - 2 * HALO;
+    constexpr int NW = TH + 2 * MH;
+    constexpr int PX = TH * TW / COLS;  // pixels per lane in the refresh role
+    static_assert((TH * TW) % COLS == 0, "pixels per lane must be whole");
+    __shared__ __attribute__((aligned(16))) float sm[2][5][TH][COLS];
+    const int role = threadIdx.x / COLS;  // wave-uniform
+    const int tid = threadIdx.x - role * COLS;
+    const WinCoef& c = a.c;
+    const int ntx = (a.w + TW - 1) / TW, nty = (a.h + TH - 1) / TH;
+    const int tiles_per_pair = ntx * nty;
+    const int strips_per_pair = (tiles_per_pair + tps - 1) / tps;
+    // XCD-aware linear workgroup id -> (pair, strip)
+    int bid;
+    {
+        const unsigned n = gridDim.x;
+        unsigned b = blockIdx.x;
+        const unsigned xcd = b & 7u, q = n >> 3, r = n & 7u;
+        bid = (int)((xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3));
+    }
+    const int z = bid / strips_per_pair;
+    const int t0 = (bid - z * strips_per_pair) * tps;
+    const int nt = min(tps, tiles_per_pair - t0);
+    const float* __restrict__ Min = a.Min + (long long)z * 5 * a.ps;
+    float* __restrict__ Mout = a.Mout + (long long)z * 5 * a.ps;
+    float* __restrict__ flow = a.flow + (long long)z * 2 * a.fps;
+    const float* __restrict__ R0 = a.R + (long long)(2 * z) * 5 * a.ps;
+    const float* __restrict__ R1 = R0 + 5 * a.ps;
+
+    constexpr int GROUPS = TW / 4;
+    constexpr int NITEM = TH * GROUPS;
+    constexpr int ROUNDS = (NITEM + COLS - 1) / COLS;
+    constexpr int WL = 4 + 2 * HALO;
+
+    // solve (+ refresh) of pixels [p0, p1) of this lane in tile (x0,y0), blurred sums in sm[buf]
+    auto refresh_px = [&](int buf, int x0, int y0, int p0, int p1) {
+#pragma unroll 2
+        for (int pi = p0; pi < p1; pi++) {
+            const int p = tid + pi * COLS;
+            const int r = p / TW, cx = p - r * TW;
+            const int x = x0 + cx, y = y0 + r;
+            if (x >= a.w || y >= a.h) continue;
+            const double g11 = sm[buf][0][r][HALO + cx], g12 = sm[buf][1][r][HALO + cx], g22 = sm[buf][2][r][HALO + cx],
+                         h1 = sm[buf][3][r][HALO + cx], h2 = sm[buf][4][r][HALO + cx];
+            const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
+            const float fxv = (float)((g11 * h2 - g12 * h1) * idet);
+            const float fyv = (float)((g22 * h1 - g12 * h2) * idet);
+            const long long o = (long long)y * a.ld + x;
+            flow[o] = fxv;
+            flow[o + a.fps] = fyv;
+            if (a.update) {
+                float M[5];
+                update_matrices_px(R0, R1, a.ps, a.ld, a.w, a.h, x, y, fxv, fyv, M);
+#pragma unroll
+                for (int cc = 0; cc < 5; cc++) Mout[o + cc * a.ps] = M[cc];
+            }
+        }
+    };
+
+    // Each role runs its own loop; both execute exactly 3 workgroup barriers per step for nt+1 steps (the
+    // hardware barrier counts arrivals, the two roles never need to be at the same program counter).
+    if (role == 0) {
+        // ================= blur role: tile `step` -> sm[step&1] =================
+        for (int step = 0; step <= nt; step++) {
+            const int buf = step & 1;
+            const bool on = step < nt;
+            const int tb = t0 + min(step, nt - 1);
+            const int x0 = (tb % ntx) * TW, y0 = (tb / ntx) * TH;
+            f32x4 res[ROUNDS][5];
+            if (on) {
+                const unsigned xb = (unsigned)clampi(x0 - HALO + tid, 0, a.w - 1) * 4u;
+                unsigned ro[NW];
+#pragma unroll
+                for (int i = 0; i < NW; i++) ro[i] = (unsigned)clampi(y0 - MH + i, 0, a.h - 1) * ((unsigned)a.ld * 4u);
+                float wa[NW], wb[NW];
+                {
+                    const __amdgpu_buffer_rsrc_t rs = make_rsrc(Min);
+#pragma unroll
+                    for (int i = 0; i < NW; i++) wa[i] = bload(rs, xb, ro[i]);
+                }
+#pragma unroll
+                for (int ch = 0; ch < 5; ch++) {
+                    float* cur = (ch & 1) ? wb : wa;
+                    float* nxt = (ch & 1) ? wa : wb;
+                    if (ch < 4) {
+                        const __amdgpu_buffer_rsrc_t rs = make_rsrc(Min + (long long)(ch + 1) * a.ps);
+#pragma unroll
+                        for (int i = 0; i < NW; i++) nxt[i] = bload(rs, xb, ro[i]);
+                    }
+#pragma unroll
+                    for (int r = 0; r < TH; r++) {
+                        float s0 = cur[r + MH] * c.k[0];
+#pragma unroll
+                        for (int i = 1; i <= MH; i++) s0 += (cur[r + MH + i] + cur[r + MH - i]) * c.k[i];
+                        sm[buf][ch][r][tid] = s0;
+                        if (r & 1) __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+            __syncthreads();
+            if (on) {
+#pragma unroll
+                for (int rd = 0; rd < ROUNDS; rd++) {
+                    const int it = tid + rd * COLS;
+                    // IR-level fence: without it the LDS reads of the next round are speculated above this
+                    // round (45 x 16 B live = 180 VGPRs)
+                    asm volatile("" ::: "memory");
+                    if (it < NITEM) {
+                        const int r = it / GROUPS, q = it - r * GROUPS;
+#pragma unroll
+                        for (int ch = 0; ch < 5; ch++) {
+                            float v[WL];
+#pragma unroll
+                            for (int u = 0; u < WL / 4; u++) {
+                                const f32x4 A = *(const f32x4*)&sm[buf][ch][r][4 * q + 4 * u];
+                                v[4 * u] = A[0];
+                                v[4 * u + 1] = A[1];
+                                v[4 * u + 2] = A[2];
+                                v[4 * u + 3] = A[3];
+                            }
+#pragma unroll
+                            for (int j = 0; j < 4; j++) {
+                                const int li = HALO + j;
+                                float sum = v[li] * c.k[0];
+#pragma unroll
+                                for (int i = 1; i <= MH; i++) sum += c.k[i] * (v[li - i] + v[li + i]);
+                                res[rd][ch][j] = sum;
+                                if (j & 1) __builtin_amdgcn_sched_barrier(0);
+                            }
+                            // pin this plane's results here: otherwise the whole round is sunk below the next
+                            // round and its 45 window loads stay live (180 VGPRs)
+                            asm volatile("" : "+v"(res[rd][ch]));
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            if (on) {
+#pragma unroll
+                for (int rd = 0; rd < ROUNDS; rd++) {
+                    const int it = tid + rd * COLS;
+                    if (it < NITEM) {
+                        const int r = it / GROUPS, q = it - r * GROUPS;
+#pragma unroll
+                        for (int ch = 0; ch < 5; ch++) *(f32x4*)&sm[buf][ch][r][HALO + 4 * q] = res[rd][ch];
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    } else {
+        // ================= refresh role: tile `step-1` <- sm[(step-1)&1] =================
+        for (int step = 0; step <= nt; step++) {
+            const int buf = (step & 1) ^ 1;
+            const int tr = t0 + max(step - 1, 0);
+            const int rx0 = (tr % ntx) * TW, ry0 = (tr / ntx) * TH;
+            if (step >= 1) refresh_px(buf, rx0, ry0, 0, (PX + 1) / 2);
+            __syncthreads();
+            if (step >= 1) refresh_px(buf, rx0, ry0, (PX + 1) / 2, PX);
+            __syncthreads();
+            __syncthreads();
+        }
+    }
+}
+
 // Generic window size (any m <= 32): same arithmetic, runtime loops, one pixel per thread, no register
 // window.  Slow path for non-default winSize.
 __global__ __launch_bounds__(256) void tw_blur_solve_generic(BlurArgs a)
