@@ -241,6 +241,25 @@ def test_non_default_parameters(twflow, oracle, kw):
     assert_same(gy, wy, "flowy %r" % kw)
 
 
+def test_config5_parameters_reduced_size(twflow, oracle):
+    """BASELINE config 5 parameters (pyrLevels 5, winSize 50, iters 5) on a 960x540 pair: 5 pyramid levels
+    (39-tap smoothing at the coarsest), 51-tap window kernels, batch of two."""
+    import synth
+    kw = dict(pyrLevels=5, winSize=50, pyrIterations=5)
+    pairs = [synth.make_pair(i, 540, 960) for i in (0, 2)]
+    with twflow.Engine(0, twflow.default_params(**kw), slots=2) as e:
+        assert e.num_levels(960, 540) == 4
+        tickets = [e.submit(a, b) for a, b in pairs]
+        got = [e.wait(t) for t in tickets]
+        gx, gy, _ = e.calculate_internal(*pairs[0])
+    for (a, b), r in zip(pairs, got):
+        wx, wy = oracle.farneback(a, b, oracle.default_params(**kw))
+        assert r["vector"] == oracle.span_scan(wx, wy, 10, 5.0)
+    wx, wy = oracle.farneback(pairs[0][0], pairs[0][1], oracle.default_params(**kw))
+    assert_same(gx, wx, "config-5 flowx")
+    assert_same(gy, wy, "config-5 flowy")
+
+
 def test_strided_input_and_errors(engine, twflow, oracle):
     rng = np.random.default_rng(5)
     big = rand_img(rng, 100, 300)

@@ -284,6 +284,7 @@ struct tw_engine {
                            // include the co-running kernel
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int blur_dbg = 0;      // TW_BLUR_DBG: timing experiments of tw_blur_solve8 (0x100 no loads, 0x200 no solve phase)
     int blur_tps = 4;      // tiles per strip of the wave-specialised kernel (TW_BLUR_TPS)
     int pyr_generic = 0;   // TW_PYR_GENERIC=1: always the generic pyramid kernel (A/B, parity cross-check)
     int blur_variant = 6;  // 6: v4 structure, refresh fused into the solve phase (default); 7: v4 + separate refresh; 0-5, 8-10: earlier structures / ILP sweeps kept for A/B
@@ -686,14 +687,27 @@ void launch_blur(tw_engine* e, hipStream_t st, int w, int h, int ld, long long p
     a.ps = ps;
     a.fps = ps;
     a.update = update;
-    a.m = e->win_m;
+    a.m = e->win_m | e->blur_dbg;
     a.c = e->wc;
     const int gy = (h + BS_TH - 1) / BS_TH;
     const bool wide = w > 480;
     bool fused = true;
     {
         ProfScope pscope(e, st, TW_K_BLUR_SOLVE, level);
-        if (e->win_m == 15 && e->blur_variant == 11 && update) {
+        if (e->win_m == 15 && (e->blur_variant == 13 || e->blur_variant == 14)) {
+            // v8: v4 tiling + packed f32 (13: next plane prefetched, 14: single register window)
+            if (e->blur_variant == 13) {
+                if (wide) hipLaunchKernelGGL((tw_blur_solve8<15, 256, 16, 8, true, true>), dim3((w + 223) / 224, gy, npairs), dim3(256), 0, st, a);
+                else hipLaunchKernelGGL((tw_blur_solve8<15, 128, 16, 8, true, true>), dim3((w + 95) / 96, gy, npairs), dim3(128), 0, st, a);
+            } else {
+                if (wide) hipLaunchKernelGGL((tw_blur_solve8<15, 256, 16, 8, true, false>), dim3((w + 223) / 224, gy, npairs), dim3(256), 0, st, a);
+                else hipLaunchKernelGGL((tw_blur_solve8<15, 128, 16, 8, true, false>), dim3((w + 95) / 96, gy, npairs), dim3(128), 0, st, a);
+            }
+        } else if (e->win_m == 15 && e->blur_variant == 12) {
+            // v6: packed-f32 structure (two pixels per VALU instruction), refresh fused
+            if (wide) hipLaunchKernelGGL((tw_blur_solve6<15, 256, 16, 8, true>), dim3((w + 223) / 224, gy, npairs), dim3(128), 0, st, a);
+            else hipLaunchKernelGGL((tw_blur_solve6<15, 128, 16, 8, true>), dim3((w + 95) / 96, gy, npairs), dim3(64), 0, st, a);
+        } else if (e->win_m == 15 && e->blur_variant == 11 && update) {
             // v5: wave-specialised fused kernel for refreshing iterations (the last iteration uses v4)
             const int tps = e->blur_tps;
             if (wide) {
@@ -754,6 +768,10 @@ void launch_blur(tw_engine* e, hipStream_t st, int w, int h, int ld, long long p
         } else if (e->win_m == 15) {
             if (wide) hipLaunchKernelGGL((tw_blur_solve<15, 256, 16>), dim3((w + 223) / 224, gy, npairs), dim3(256), 0, st, a);
             else hipLaunchKernelGGL((tw_blur_solve<15, 128, 16>), dim3((w + 95) / 96, gy, npairs), dim3(128), 0, st, a);
+        } else if (e->win_m == 25 && e->blur_variant != 0) {
+            // winSize 50/51 (BASELINE config 5): packed-f32 structure, single register window (58 rows)
+            if (wide) hipLaunchKernelGGL((tw_blur_solve8<25, 256, 32, 8, true, false>), dim3((w + 191) / 192, gy, npairs), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((tw_blur_solve8<25, 128, 32, 8, true, false>), dim3((w + 63) / 64, gy, npairs), dim3(128), 0, st, a);
         } else if (e->win_m == 25) {
             if (wide) hipLaunchKernelGGL((tw_blur_solve<25, 256, 32>), dim3((w + 191) / 192, gy, npairs), dim3(256), 0, st, a);
             else hipLaunchKernelGGL((tw_blur_solve<25, 128, 32>), dim3((w + 63) / 64, gy, npairs), dim3(128), 0, st, a);
@@ -1081,6 +1099,7 @@ tw_status tw_engine_create(int device, const tw_params* params, int slots, tw_en
     e->win_m = p.winSize / 2;
     if (const char* ev = getenv("TW_BLUR_VARIANT")) e->blur_variant = atoi(ev);
     if (const char* ev = getenv("TW_PYR_GENERIC")) e->pyr_generic = atoi(ev);
+    if (const char* ev = getenv("TW_BLUR_DBG")) e->blur_dbg = (int)strtol(ev, nullptr, 0);
     if (const char* ev = getenv("TW_BLUR_TPS")) e->blur_tps = std::max(1, atoi(ev));
     if (const char* ev = getenv("TW_LANES")) e->lanes = std::min(2, std::max(1, atoi(ev)));
     bool ok = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) == hipSuccess &&
@@ -1410,6 +1429,25 @@ tw_status down_planes(tw_engine* e, float* h, const float* d, int ld, long long 
 }
 }  // namespace
 
+
+// occupancy report of the main kernels (workgroups per CU the runtime admits) — tools/kbench.py
+extern "C" int tw_debug_occupancy(char* buf, int cap)
+{
+    int n = 0, o = 0;
+    auto add = [&](const char* name, const void* fn, int threads, size_t dyn_lds) {
+        int blocks = -1;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, fn, threads, dyn_lds);
+        o = snprintf(buf + n, cap - n, "%s: %d workgroups/CU of %d threads\n", name, blocks, threads);
+        if (o > 0) n += o;
+    };
+    add("tw_blur_solve4<15,256>", (const void*)tw_blur_solve4<15, 256, 16, 8, true>, 256, 0);
+    add("tw_blur_solve8<15,256>", (const void*)tw_blur_solve8<15, 256, 16, 8, true, true>, 256, 0);
+    add("tw_blur_solve8<15,128>", (const void*)tw_blur_solve8<15, 128, 16, 8, true, true>, 128, 0);
+    add("tw_polyexp<7>", (const void*)tw_polyexp<7>, 256, 0);
+    add("tw_update_matrices<true>", (const void*)tw_update_matrices<true>, 256, 0);
+    add("tw_pyr_k3<0>", (const void*)tw_pyr_k3<0>, 256, 0);
+    return n;
+}
 
 // ---- isolated kernel timing on synthetic device data (bench.py, tools/kbench.py) -------------------------
 extern "C" tw_status tw_bench_stage(tw_engine* e, int kclass, int width, int height, int level, int npairs,

@@ -43,6 +43,12 @@ __device__ __forceinline__ float bload(__amdgpu_buffer_rsrc_t r, unsigned voff, 
 {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
 }
+typedef float __attribute__((ext_vector_type(2))) f32x2;
+typedef unsigned __attribute__((ext_vector_type(2))) u32x2;
+__device__ __forceinline__ f32x2 bload2(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+{
+    return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+}
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
@@ -1395,6 +1401,371 @@ __global__ __launch_bounds__(2 * COLS) void tw_blur_solve5(BlurArgs a, int tps /
             if (step >= 1) refresh_px(buf, rx0, ry0, (PX + 1) / 2, PX);
             __syncthreads();
             __syncthreads();
+        }
+    }
+}
+
+// -----------------------------------------------------------------------------------------------------
+// tw_blur_solve6<MH,COLS,HALO,TH,FUSED> : packed-f32 version of v4.
+//   On gfx950 every wave64 VALU instruction occupies its SIMD for ~4.3 cycles — v_pk_add_f32 / v_pk_mul_f32
+//   included (tools/ubench/valu_rate.hip, valu_dep.hip) — so two independent pixels per instruction halve the
+//   cost of the window average, which is pure non-fusable add/mul work (v4 already runs the VALU ~100 % busy).
+//   Pairs are chosen so that operands are naturally even-aligned register pairs (no shuffles):
+//     V : a lane owns two adjacent COLUMNS (8-byte loads);  s{x,x+1} += (w[a]{x,x+1} + w[b]{x,x+1}) * k
+//     H : an item owns 4 pixels of two adjacent ROWS; LDS holds float2 {row 2p, row 2p+1} per column
+//     S : a lane solves the two vertically adjacent pixels of a column (lane-consecutive x)
+//   IEEE add/mul per component, same order as the CPU code: results stay bit-identical.
+//   COLS/2 threads per workgroup, 40 KB LDS -> 4 workgroups (8 waves) per CU; the VGPR budget of 2 waves per
+//   SIMD pays for two prefetched register windows.
+// -----------------------------------------------------------------------------------------------------
+template <int MH, int COLS, int HALO, int TH, bool FUSED>
+__global__ __launch_bounds__(COLS / 2) void tw_blur_solve6(BlurArgs a)
+{
+    constexpr int NT = COLS / 2;          // threads
+    constexpr int TW = COLS - 2 * HALO;   // output columns
+    constexpr int NW = TH + 2 * MH;       // window rows
+    constexpr int RP = TH / 2;            // row pairs
+    static_assert(TH % 4 == 0 && HALO % 4 == 0 && TW % 4 == 0, "tile shape");
+    __shared__ __attribute__((aligned(16))) f32x2 sm[5][RP][COLS];  // {row 2p, row 2p+1} per column
+    const int tid = threadIdx.x;
+    int bx, by, z;
+    xcd_remap(bx, by, z);
+    const int x0 = bx * TW, y0 = by * TH;
+    const WinCoef& c = a.c;
+    const float* __restrict__ Min = a.Min + (long long)z * 5 * a.ps;
+    float* __restrict__ flow = a.flow + (long long)z * 2 * a.fps;
+
+    // ---- V: two adjacent columns per lane ----
+    {
+        const int c0 = 2 * tid;
+        const int xg = x0 - HALO + c0;
+        const bool pair_ok = (xg >= 0) && (xg + 1 <= a.w - 1);
+        const bool all_ok = __all(pair_ok);  // wave-uniform: 8-byte loads for the whole wave
+        const unsigned xb0 = (unsigned)clampi(xg, 0, a.w - 1) * 4u, xb1 = (unsigned)clampi(xg + 1, 0, a.w - 1) * 4u;
+        unsigned ro[NW];
+#pragma unroll
+        for (int i = 0; i < NW; i++) ro[i] = (unsigned)clampi(y0 - MH + i, 0, a.h - 1) * ((unsigned)a.ld * 4u);
+        f32x2 wa[NW], wb[NW];
+        auto load_plane = [&](int ch, f32x2* w) {
+            const __amdgpu_buffer_rsrc_t rs = make_rsrc(Min + (long long)ch * a.ps);
+            if (all_ok) {
+#pragma unroll
+                for (int i = 0; i < NW; i++) w[i] = bload2(rs, xb0, ro[i]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < NW; i++) {
+                    w[i].x = bload(rs, xb0, ro[i]);
+                    w[i].y = bload(rs, xb1, ro[i]);
+                }
+            }
+        };
+        load_plane(0, wa);
+#pragma unroll
+        for (int ch = 0; ch < 5; ch++) {
+            f32x2* cur = (ch & 1) ? wb : wa;
+            f32x2* nxt = (ch & 1) ? wa : wb;
+            if (ch < 4) load_plane(ch + 1, nxt);
+#pragma unroll
+            for (int rp = 0; rp < RP; rp += 2) {
+                // four output rows advance in lockstep: independent chains between dependent packed ops
+                // (a dependent v_pk pair otherwise costs an s_nop each)
+                f32x2 s[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) s[q] = cur[2 * rp + q + MH] * c.k[0];
+#pragma unroll
+                for (int i = 1; i <= MH; i++) {
+                    f32x2 t[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) t[q] = cur[2 * rp + q + MH + i] + cur[2 * rp + q + MH - i];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) t[q] = t[q] * c.k[i];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) s[q] += t[q];
+                }
+                *(f32x4*)&sm[ch][rp][c0] = f32x4{s[0].x, s[1].x, s[0].y, s[1].y};
+                *(f32x4*)&sm[ch][rp + 1][c0] = f32x4{s[2].x, s[3].x, s[2].y, s[3].y};
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- H: 4 pixels x 2 rows per item, all planes, results in registers ----
+    constexpr int GROUPS = TW / 4;
+    constexpr int NITEM = RP * GROUPS;
+    constexpr int ROUNDS = (NITEM + NT - 1) / NT;
+    constexpr int WL = 4 + 2 * HALO;
+    f32x2 res[ROUNDS][5][4];
+#pragma unroll
+    for (int rd = 0; rd < ROUNDS; rd++) {
+        const int it = tid + rd * NT;
+        if (it < NITEM) {
+            const int rp = it / GROUPS, q = it - rp * GROUPS;
+#pragma unroll
+            for (int ch = 0; ch < 5; ch++) {
+                f32x2 v[WL];
+#pragma unroll
+                for (int u = 0; u < WL / 2; u++) {
+                    const f32x4 A = *(const f32x4*)&sm[ch][rp][4 * q + 2 * u];
+                    v[2 * u] = f32x2{A[0], A[1]};
+                    v[2 * u + 1] = f32x2{A[2], A[3]};
+                }
+                {
+                    f32x2 sum[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) sum[j] = v[HALO + j] * c.k[0];
+#pragma unroll
+                    for (int i = 1; i <= MH; i++) {
+                        f32x2 t[4];
+#pragma unroll
+                        for (int j = 0; j < 4; j++) t[j] = v[HALO + j - i] + v[HALO + j + i];
+#pragma unroll
+                        for (int j = 0; j < 4; j++) t[j] = c.k[i] * t[j];
+#pragma unroll
+                        for (int j = 0; j < 4; j++) sum[j] += t[j];
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; j++) res[rd][ch][j] = sum[j];
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            // pin: keeps this round from being sunk below the next one (its windows would stay live)
+#pragma unroll
+            for (int ch = 0; ch < 5; ch++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) asm volatile("" : "+v"(res[rd][ch][j]));
+        }
+    }
+    __syncthreads();  // every window has been read: the interiors may be overwritten
+#pragma unroll
+    for (int rd = 0; rd < ROUNDS; rd++) {
+        const int it = tid + rd * NT;
+        if (it < NITEM) {
+            const int rp = it / GROUPS, q = it - rp * GROUPS;
+#pragma unroll
+            for (int ch = 0; ch < 5; ch++) {
+                *(f32x4*)&sm[ch][rp][HALO + 4 * q] =
+                    f32x4{res[rd][ch][0].x, res[rd][ch][0].y, res[rd][ch][1].x, res[rd][ch][1].y};
+                *(f32x4*)&sm[ch][rp][HALO + 4 * q + 2] =
+                    f32x4{res[rd][ch][2].x, res[rd][ch][2].y, res[rd][ch][3].x, res[rd][ch][3].y};
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- S: solve (+ refresh): a lane takes the two vertically adjacent pixels of a column ----
+    float* __restrict__ Mout = a.Mout + (long long)z * 5 * a.ps;
+    const float* __restrict__ R0 = a.R + (long long)(2 * z) * 5 * a.ps;
+    const float* __restrict__ R1 = R0 + 5 * a.ps;
+    static_assert((RP * TW) % NT == 0, "column pairs per lane must be whole");
+#pragma unroll 1
+    for (int p = tid; p < RP * TW; p += NT) {
+        const int rp = p / TW, cx = p - rp * TW;
+        const int x = x0 + cx;
+        if (x >= a.w) continue;
+        f32x2 b[5];
+#pragma unroll
+        for (int ch = 0; ch < 5; ch++) b[ch] = sm[ch][rp][HALO + cx];
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const int y = y0 + 2 * rp + q;
+            if (y >= a.h) break;
+            const double g11 = b[0][q], g12 = b[1][q], g22 = b[2][q], h1 = b[3][q], h2 = b[4][q];
+            const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
+            const float fxv = (float)((g11 * h2 - g12 * h1) * idet);
+            const float fyv = (float)((g22 * h1 - g12 * h2) * idet);
+            const long long o = (long long)y * a.ld + x;
+            flow[o] = fxv;
+            flow[o + a.fps] = fyv;
+            if (FUSED) {
+                if (a.update) {
+                    float M[5];
+                    update_matrices_px(R0, R1, a.ps, a.ld, a.w, a.h, x, y, fxv, fyv, M);
+#pragma unroll
+                    for (int cc = 0; cc < 5; cc++) Mout[o + cc * a.ps] = M[cc];
+                }
+            }
+        }
+    }
+}
+
+// -----------------------------------------------------------------------------------------------------
+// tw_blur_solve8<MH,COLS,HALO,TH,FUSED,PREFETCH> : v4's tiling and occupancy (COLS threads, 40 KB LDS, 4
+//   workgroups = 16 waves per CU) with packed f32 arithmetic (see v6 for why):
+//     V : one column per lane; output rows are produced in PAIRS (r, r+1): the window is held as even-aligned
+//         pairs {w[2j], w[2j+1]} plus a copy shifted by one row {w[2j+1], w[2j+2]}, so every tap of a row pair
+//         is one aligned register pair;  {s_r, s_r+1} += ({w[a], w[a+1]} + {w[b], w[b+1]}) * k
+//     H : an item owns 4 pixels of a row pair; LDS holds float2 {row 2p, row 2p+1} per column
+//     S : a lane solves the two vertically adjacent pixels of a column (lane-consecutive x), refresh fused
+// -----------------------------------------------------------------------------------------------------
+template <int MH, int COLS, int HALO, int TH, bool FUSED, bool PREFETCH>
+__global__ __launch_bounds__(COLS) void tw_blur_solve8(BlurArgs a)
+{
+    constexpr int TW = COLS - 2 * HALO;
+    constexpr int NW = TH + 2 * MH;      // window rows (even)
+    constexpr int NP = NW / 2;           // even-aligned pairs
+    constexpr int RP = TH / 2;
+    static_assert(NW % 2 == 0 && TH % 2 == 0 && TW % 4 == 0 && HALO % 2 == 0, "tile shape");
+    __shared__ __attribute__((aligned(16))) f32x2 sm[5][RP][COLS];  // {row 2p, row 2p+1} per column
+    const int tid = threadIdx.x;
+    int bx, by, z;
+    xcd_remap(bx, by, z);
+    const int x0 = bx * TW, y0 = by * TH;
+    const WinCoef& c = a.c;
+    const float* __restrict__ Min = a.Min + (long long)z * 5 * a.ps;
+    float* __restrict__ flow = a.flow + (long long)z * 2 * a.fps;
+
+    // ---- V ----
+    {
+        const unsigned xb = (unsigned)clampi(x0 - HALO + tid, 0, a.w - 1) * 4u;
+        unsigned ro[NW];
+#pragma unroll
+        for (int i = 0; i < NW; i++) ro[i] = (unsigned)clampi(y0 - MH + i, 0, a.h - 1) * ((unsigned)a.ld * 4u);
+        f32x2 wa[NP], wb[NP];
+        auto load_plane = [&](int ch, f32x2* w) {
+            const __amdgpu_buffer_rsrc_t rs = make_rsrc(Min + (long long)ch * a.ps);
+            if (a.m & 0x100) {  // timing experiment (tools/kbench.py only): no global loads
+#pragma unroll
+                for (int i = 0; i < NP; i++) w[i] = f32x2{(float)(i + tid + ch), (float)(i - tid)};
+                return;
+            }
+#pragma unroll
+            for (int i = 0; i < NP; i++) {
+                w[i].x = bload(rs, xb, ro[2 * i]);
+                w[i].y = bload(rs, xb, ro[2 * i + 1]);
+            }
+        };
+        load_plane(0, wa);
+#pragma unroll
+        for (int ch = 0; ch < 5; ch++) {
+            f32x2* we = (!PREFETCH || !(ch & 1)) ? wa : wb;
+            if (PREFETCH) {
+                if (ch < 4) load_plane(ch + 1, (ch & 1) ? wa : wb);
+            }
+            // window shifted by one row: wo[j] = {w[2j+1], w[2j+2]}
+            f32x2 wo[NP - 1];
+#pragma unroll
+            for (int j = 0; j < NP - 1; j++) wo[j] = f32x2{we[j].y, we[j + 1].x};
+            // pair starting at window row t (any parity)
+            auto P = [&](int t) -> f32x2 { return (t & 1) ? wo[t >> 1] : we[t >> 1]; };
+#pragma unroll
+            for (int rp = 0; rp < RP; rp += 2) {
+                // two row pairs (4 output rows) advance in lockstep
+                f32x2 s0 = P(2 * rp + MH) * c.k[0], s1 = P(2 * rp + 2 + MH) * c.k[0];
+#pragma unroll
+                for (int i = 1; i <= MH; i++) {
+                    f32x2 t0 = P(2 * rp + MH + i) + P(2 * rp + MH - i);
+                    f32x2 t1 = P(2 * rp + 2 + MH + i) + P(2 * rp + 2 + MH - i);
+                    t0 = t0 * c.k[i];
+                    t1 = t1 * c.k[i];
+                    s0 += t0;
+                    s1 += t1;
+                }
+                sm[ch][rp][tid] = s0;
+                sm[ch][rp + 1][tid] = s1;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (!PREFETCH) {
+                if (ch < 4) load_plane(ch + 1, wa);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- H: 4 pixels x 2 rows per item, all planes, results in registers ----
+    constexpr int GROUPS = TW / 4;
+    constexpr int NITEM = RP * GROUPS;
+    constexpr int ROUNDS = (NITEM + COLS - 1) / COLS;
+    constexpr int WL = 4 + 2 * HALO;
+    f32x2 res[ROUNDS][5][4];
+#pragma unroll
+    for (int rd = 0; rd < ROUNDS; rd++) {
+        const int it = tid + rd * COLS;
+        if (it < NITEM) {
+            const int rp = it / GROUPS, q = it - rp * GROUPS;
+#pragma unroll
+            for (int ch = 0; ch < 5; ch++) {
+                f32x2 v[WL];
+#pragma unroll
+                for (int u = 0; u < WL / 2; u++) {
+                    const f32x4 A = *(const f32x4*)&sm[ch][rp][4 * q + 2 * u];
+                    v[2 * u] = f32x2{A[0], A[1]};
+                    v[2 * u + 1] = f32x2{A[2], A[3]};
+                }
+                {
+                    f32x2 sum[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) sum[j] = v[HALO + j] * c.k[0];
+#pragma unroll
+                    for (int i = 1; i <= MH; i++) {
+                        f32x2 t[4];
+#pragma unroll
+                        for (int j = 0; j < 4; j++) t[j] = v[HALO + j - i] + v[HALO + j + i];
+#pragma unroll
+                        for (int j = 0; j < 4; j++) t[j] = c.k[i] * t[j];
+#pragma unroll
+                        for (int j = 0; j < 4; j++) sum[j] += t[j];
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; j++) res[rd][ch][j] = sum[j];
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+#pragma unroll
+            for (int ch = 0; ch < 5; ch++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) asm volatile("" : "+v"(res[rd][ch][j]));
+        }
+    }
+    __syncthreads();  // every window has been read: the interiors may be overwritten
+#pragma unroll
+    for (int rd = 0; rd < ROUNDS; rd++) {
+        const int it = tid + rd * COLS;
+        if (it < NITEM) {
+            const int rp = it / GROUPS, q = it - rp * GROUPS;
+#pragma unroll
+            for (int ch = 0; ch < 5; ch++) {
+                *(f32x4*)&sm[ch][rp][HALO + 4 * q] =
+                    f32x4{res[rd][ch][0].x, res[rd][ch][0].y, res[rd][ch][1].x, res[rd][ch][1].y};
+                *(f32x4*)&sm[ch][rp][HALO + 4 * q + 2] =
+                    f32x4{res[rd][ch][2].x, res[rd][ch][2].y, res[rd][ch][3].x, res[rd][ch][3].y};
+            }
+        }
+    }
+    __syncthreads();
+
+    if (a.m & 0x200) return;  // timing experiment: V + H only
+    // ---- S: solve (+ refresh): a lane takes the two vertically adjacent pixels of a column ----
+    float* __restrict__ Mout = a.Mout + (long long)z * 5 * a.ps;
+    const float* __restrict__ R0 = a.R + (long long)(2 * z) * 5 * a.ps;
+    const float* __restrict__ R1 = R0 + 5 * a.ps;
+#pragma unroll 1
+    for (int p = tid; p < RP * TW; p += COLS) {
+        const int rp = p / TW, cx = p - rp * TW;
+        const int x = x0 + cx;
+        if (x >= a.w) continue;
+        f32x2 b[5];
+#pragma unroll
+        for (int ch = 0; ch < 5; ch++) b[ch] = sm[ch][rp][HALO + cx];
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const int y = y0 + 2 * rp + q;
+            if (y >= a.h) break;
+            const double g11 = b[0][q], g12 = b[1][q], g22 = b[2][q], h1 = b[3][q], h2 = b[4][q];
+            const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
+            const float fxv = (float)((g11 * h2 - g12 * h1) * idet);
+            const float fyv = (float)((g22 * h1 - g12 * h2) * idet);
+            const long long o = (long long)y * a.ld + x;
+            flow[o] = fxv;
+            flow[o + a.fps] = fyv;
+            if (FUSED) {
+                if (a.update) {
+                    float M[5];
+                    update_matrices_px(R0, R1, a.ps, a.ld, a.w, a.h, x, y, fxv, fyv, M);
+#pragma unroll
+                    for (int cc = 0; cc < 5; cc++) Mout[o + cc * a.ps] = M[cc];
+                }
+            }
         }
     }
 }
