@@ -58,7 +58,7 @@ def cpu_baseline(pairs):
     O.lib()
     cores = os.cpu_count() or 1
     threads = min(cores, 16)
-    njobs = threads
+    njobs = 2 * threads  # ~25-30 core-seconds of CPU work
     jobs = list(range(njobs))
     lock = threading.Lock()
     out = {}
@@ -81,7 +81,7 @@ def cpu_baseline(pairs):
         t.join()
     dt = time.perf_counter() - t0
     return {"value": njobs / dt, "unit": "pairs/s", "cores": threads, "kind": "port",
-            "sample": "%d x 1920x1080 synthetic pairs, one per thread, %d threads of %d host cores, %.1f s wall"
+            "sample": "%d x 1920x1080 synthetic pairs pulled from one queue by %d threads (of %d host cores), %.1f s wall"
                       % (njobs, threads, cores, dt)}, out
 
 

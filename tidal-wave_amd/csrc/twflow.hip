@@ -284,10 +284,8 @@ struct tw_engine {
                            // include the co-running kernel
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    int blur_dbg = 0;      // TW_BLUR_DBG: timing experiments of tw_blur_solve8 (0x100 no loads, 0x200 no solve phase)
-    int blur_tps = 4;      // tiles per strip of the wave-specialised kernel (TW_BLUR_TPS)
     int pyr_generic = 0;   // TW_PYR_GENERIC=1: always the generic pyramid kernel (A/B, parity cross-check)
-    int blur_variant = 6;  // 6: v4 structure, refresh fused into the solve phase (default); 7: v4 + separate refresh; 0-5, 8-10: earlier structures / ILP sweeps kept for A/B
+    int blur_variant = 4;  // 4: tw_blur_solve4 (default); 8: tw_blur_solve8 (packed f32) — TW_BLUR_VARIANT
     std::string err;
     // device workspace, shared by all batches (execution is ordered on one stream)
     size_t ws_elems = 0;                 // capacity of I (floats); R = 5x, M = 5x each
@@ -655,24 +653,6 @@ tw_status launch_polyexp(tw_engine* e, hipStream_t st, int w, int h, int ld, lon
     return TW_OK;
 }
 
-void launch_refresh(tw_engine* e, hipStream_t st, int w, int h, int ld, long long ps, const float* R, float* flow,
-                    float* M, int level, int npairs)
-{
-    UpdArgs a;
-    memset(&a, 0, sizeof(a));
-    a.R = R;
-    a.flow = flow;
-    a.M = M;
-    a.w = w;
-    a.h = h;
-    a.ld = ld;
-    a.ps = ps;
-    a.fps = ps;
-    dim3 grid((w + 63) / 64, (h + 3) / 4, npairs);
-    ProfScope pscope(e, st, TW_K_UPDATE_MATRICES, level);
-    hipLaunchKernelGGL(tw_update_matrices<false>, grid, dim3(256), 0, st, a);
-}
-
 void launch_blur(tw_engine* e, hipStream_t st, int w, int h, int ld, long long ps, const float* Min, float* Mout,
                  float* flow, const float* R, int update, int level, int npairs)
 {
@@ -687,100 +667,27 @@ void launch_blur(tw_engine* e, hipStream_t st, int w, int h, int ld, long long p
     a.ps = ps;
     a.fps = ps;
     a.update = update;
-    a.m = e->win_m | e->blur_dbg;
+    a.m = e->win_m;
     a.c = e->wc;
     const int gy = (h + BS_TH - 1) / BS_TH;
-    const bool wide = w > 480;
-    bool fused = true;
-    {
-        ProfScope pscope(e, st, TW_K_BLUR_SOLVE, level);
-        if (e->win_m == 15 && (e->blur_variant == 13 || e->blur_variant == 14)) {
-            // v8: v4 tiling + packed f32 (13: next plane prefetched, 14: single register window)
-            if (e->blur_variant == 13) {
-                if (wide) hipLaunchKernelGGL((tw_blur_solve8<15, 256, 16, 8, true, true>), dim3((w + 223) / 224, gy, npairs), dim3(256), 0, st, a);
-                else hipLaunchKernelGGL((tw_blur_solve8<15, 128, 16, 8, true, true>), dim3((w + 95) / 96, gy, npairs), dim3(128), 0, st, a);
-            } else {
-                if (wide) hipLaunchKernelGGL((tw_blur_solve8<15, 256, 16, 8, true, false>), dim3((w + 223) / 224, gy, npairs), dim3(256), 0, st, a);
-                else hipLaunchKernelGGL((tw_blur_solve8<15, 128, 16, 8, true, false>), dim3((w + 95) / 96, gy, npairs), dim3(128), 0, st, a);
-            }
-        } else if (e->win_m == 15 && e->blur_variant == 12) {
-            // v6: packed-f32 structure (two pixels per VALU instruction), refresh fused
-            if (wide) hipLaunchKernelGGL((tw_blur_solve6<15, 256, 16, 8, true>), dim3((w + 223) / 224, gy, npairs), dim3(128), 0, st, a);
-            else hipLaunchKernelGGL((tw_blur_solve6<15, 128, 16, 8, true>), dim3((w + 95) / 96, gy, npairs), dim3(64), 0, st, a);
-        } else if (e->win_m == 15 && e->blur_variant == 11 && update) {
-            // v5: wave-specialised fused kernel for refreshing iterations (the last iteration uses v4)
-            const int tps = e->blur_tps;
-            if (wide) {
-                const int tiles = ((w + 223) / 224) * gy;
-                hipLaunchKernelGGL((tw_blur_solve5<15, 256, 16, 8>), dim3(((tiles + tps - 1) / tps) * npairs), dim3(512), 0, st, a, tps);
-            } else {
-                const int tiles = ((w + 95) / 96) * gy;
-                hipLaunchKernelGGL((tw_blur_solve5<15, 128, 16, 8>), dim3(((tiles + tps - 1) / tps) * npairs), dim3(256), 0, st, a, tps);
-            }
-        } else if (e->win_m == 15 && e->blur_variant == 11) {
-            if (wide) hipLaunchKernelGGL((tw_blur_solve4<15, 256, 16, 8, true>), dim3((w + 223) / 224, gy, npairs), dim3(256), 0, st, a);
-            else hipLaunchKernelGGL((tw_blur_solve4<15, 128, 16, 8, true>), dim3((w + 95) / 96, gy, npairs), dim3(128), 0, st, a);
-        } else if (e->win_m == 15 && e->blur_variant >= 8 && e->blur_variant <= 10) {
-            // ILP sweeps of the v4 structure (fused refresh)
-            if (e->blur_variant == 8) {
-                if (wide) hipLaunchKernelGGL((tw_blur_solve4<15, 256, 16, 8, true, 4, 4>), dim3((w + 223) / 224, gy, npairs), dim3(256), 0, st, a);
-                else hipLaunchKernelGGL((tw_blur_solve4<15, 128, 16, 8, true, 4, 4>), dim3((w + 95) / 96, gy, npairs), dim3(128), 0, st, a);
-            } else if (e->blur_variant == 9) {
-                if (wide) hipLaunchKernelGGL((tw_blur_solve4<15, 256, 16, 8, true, 8, 4>), dim3((w + 223) / 224, gy, npairs), dim3(256), 0, st, a);
-                else hipLaunchKernelGGL((tw_blur_solve4<15, 128, 16, 8, true, 8, 4>), dim3((w + 95) / 96, gy, npairs), dim3(128), 0, st, a);
-            } else {
-                if (wide) hipLaunchKernelGGL((tw_blur_solve4<15, 256, 16, 8, true, 1, 1>), dim3((w + 223) / 224, gy, npairs), dim3(256), 0, st, a);
-                else hipLaunchKernelGGL((tw_blur_solve4<15, 128, 16, 8, true, 1, 1>), dim3((w + 95) / 96, gy, npairs), dim3(128), 0, st, a);
-            }
-        } else if (e->win_m == 15 && (e->blur_variant == 6 || e->blur_variant == 7)) {
-            // v4 structure: 6 = refresh fused, 7 = separate refresh kernel
-            if (e->blur_variant == 7) {
-                fused = false;
-                if (wide) hipLaunchKernelGGL((tw_blur_solve4<15, 256, 16, 8, false>), dim3((w + 223) / 224, gy, npairs), dim3(256), 0, st, a);
-                else hipLaunchKernelGGL((tw_blur_solve4<15, 128, 16, 8, false>), dim3((w + 95) / 96, gy, npairs), dim3(128), 0, st, a);
-            } else {
-                if (wide) hipLaunchKernelGGL((tw_blur_solve4<15, 256, 16, 8, true>), dim3((w + 223) / 224, gy, npairs), dim3(256), 0, st, a);
-                else hipLaunchKernelGGL((tw_blur_solve4<15, 128, 16, 8, true>), dim3((w + 95) / 96, gy, npairs), dim3(128), 0, st, a);
-            }
-        } else if (e->win_m == 15 && (e->blur_variant == 4 || e->blur_variant == 5)) {
-            // v3 structure: 4 = separate refresh kernel, 5 = refresh fused into the solve phase
-            if (e->blur_variant == 4) {
-                fused = false;
-                if (wide) hipLaunchKernelGGL((tw_blur_solve3<15, 256, 16, 8, false>), dim3((w + 223) / 224, gy, npairs), dim3(256), 0, st, a);
-                else hipLaunchKernelGGL((tw_blur_solve3<15, 128, 16, 8, false>), dim3((w + 95) / 96, gy, npairs), dim3(128), 0, st, a);
-            } else {
-                if (wide) hipLaunchKernelGGL((tw_blur_solve3<15, 256, 16, 8, true>), dim3((w + 223) / 224, gy, npairs), dim3(256), 0, st, a);
-                else hipLaunchKernelGGL((tw_blur_solve3<15, 128, 16, 8, true>), dim3((w + 95) / 96, gy, npairs), dim3(128), 0, st, a);
-            }
-        } else if (e->win_m == 15 && e->blur_variant >= 1) {
-            fused = false;
-            if (e->blur_variant == 2) {
-                const int gy9 = (h + 8) / 9;
-                if (wide) hipLaunchKernelGGL((tw_blur_solve2<15, 256, 16, 9, 3>), dim3((w + 223) / 224, gy9, npairs), dim3(256), 0, st, a);
-                else hipLaunchKernelGGL((tw_blur_solve2<15, 128, 16, 9, 3>), dim3((w + 95) / 96, gy9, npairs), dim3(128), 0, st, a);
-            } else if (e->blur_variant == 3) {
-                if (wide) hipLaunchKernelGGL((tw_blur_solve2<15, 256, 16, 8, 4>), dim3((w + 223) / 224, gy, npairs), dim3(256), 0, st, a);
-                else hipLaunchKernelGGL((tw_blur_solve2<15, 128, 16, 8, 4>), dim3((w + 95) / 96, gy, npairs), dim3(128), 0, st, a);
-            } else {
-                if (wide) hipLaunchKernelGGL((tw_blur_solve2<15, 256, 16, 8, 2>), dim3((w + 223) / 224, gy, npairs), dim3(256), 0, st, a);
-                else hipLaunchKernelGGL((tw_blur_solve2<15, 128, 16, 8, 2>), dim3((w + 95) / 96, gy, npairs), dim3(128), 0, st, a);
-            }
-        } else if (e->win_m == 15) {
-            if (wide) hipLaunchKernelGGL((tw_blur_solve<15, 256, 16>), dim3((w + 223) / 224, gy, npairs), dim3(256), 0, st, a);
-            else hipLaunchKernelGGL((tw_blur_solve<15, 128, 16>), dim3((w + 95) / 96, gy, npairs), dim3(128), 0, st, a);
-        } else if (e->win_m == 25 && e->blur_variant != 0) {
-            // winSize 50/51 (BASELINE config 5): packed-f32 structure, single register window (58 rows)
-            if (wide) hipLaunchKernelGGL((tw_blur_solve8<25, 256, 32, 8, true, false>), dim3((w + 191) / 192, gy, npairs), dim3(256), 0, st, a);
-            else hipLaunchKernelGGL((tw_blur_solve8<25, 128, 32, 8, true, false>), dim3((w + 63) / 64, gy, npairs), dim3(128), 0, st, a);
-        } else if (e->win_m == 25) {
-            if (wide) hipLaunchKernelGGL((tw_blur_solve<25, 256, 32>), dim3((w + 191) / 192, gy, npairs), dim3(256), 0, st, a);
-            else hipLaunchKernelGGL((tw_blur_solve<25, 128, 32>), dim3((w + 63) / 64, gy, npairs), dim3(128), 0, st, a);
-        } else {
-            const size_t lds = (size_t)5 * BS_TH * (64 + 2 * e->win_m) * 4;
-            hipLaunchKernelGGL(tw_blur_solve_generic, dim3((w + 63) / 64, gy, npairs), dim3(256), lds, st, a);
-        }
+    const bool wide = w > 480;  // 224-column tiles; narrow levels use 96-column tiles (less edge waste)
+    ProfScope pscope(e, st, TW_K_BLUR_SOLVE, level);
+    if (e->win_m == 15 && e->blur_variant == 8) {
+        // packed-f32 structure (same speed as v4 at 1080p, lower VALU load); TW_BLUR_VARIANT=8 for A/B
+        if (wide) hipLaunchKernelGGL((tw_blur_solve8<15, 256, 16, 8, true, true>), dim3((w + 223) / 224, gy, npairs), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((tw_blur_solve8<15, 128, 16, 8, true, true>), dim3((w + 95) / 96, gy, npairs), dim3(128), 0, st, a);
+    } else if (e->win_m == 15) {
+        if (wide) hipLaunchKernelGGL((tw_blur_solve4<15, 256, 16, 8, true>), dim3((w + 223) / 224, gy, npairs), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((tw_blur_solve4<15, 128, 16, 8, true>), dim3((w + 95) / 96, gy, npairs), dim3(128), 0, st, a);
+    } else if (e->win_m == 25) {
+        // winSize 50/51 (BASELINE config 5): packed-f32 structure, single 58-row register window
+        if (wide) hipLaunchKernelGGL((tw_blur_solve8<25, 256, 32, 8, true, false>), dim3((w + 191) / 192, gy, npairs), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((tw_blur_solve8<25, 128, 32, 8, true, false>), dim3((w + 63) / 64, gy, npairs), dim3(128), 0, st, a);
+    } else {
+        // any other window size: generic kernel (same arithmetic, runtime loops)
+        const size_t lds = (size_t)5 * BS_TH * (64 + 2 * e->win_m) * 4;
+        hipLaunchKernelGGL(tw_blur_solve_generic, dim3((w + 63) / 64, gy, npairs), dim3(256), lds, st, a);
     }
-    if (!fused && update) launch_refresh(e, st, w, h, ld, ps, R, flow, Mout, level, npairs);
 }
 
 void launch_update(tw_engine* e, hipStream_t st, const Plan* pl, int k, const float* R, float* flow,
@@ -1099,8 +1006,6 @@ tw_status tw_engine_create(int device, const tw_params* params, int slots, tw_en
     e->win_m = p.winSize / 2;
     if (const char* ev = getenv("TW_BLUR_VARIANT")) e->blur_variant = atoi(ev);
     if (const char* ev = getenv("TW_PYR_GENERIC")) e->pyr_generic = atoi(ev);
-    if (const char* ev = getenv("TW_BLUR_DBG")) e->blur_dbg = (int)strtol(ev, nullptr, 0);
-    if (const char* ev = getenv("TW_BLUR_TPS")) e->blur_tps = std::max(1, atoi(ev));
     if (const char* ev = getenv("TW_LANES")) e->lanes = std::min(2, std::max(1, atoi(ev)));
     bool ok = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) == hipSuccess &&
               hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking) == hipSuccess &&

@@ -690,11 +690,12 @@ struct UpdArgs {
 template <bool UPSAMPLE>
 __global__ __launch_bounds__(256) void tw_update_matrices(UpdArgs a)
 {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    int bx, by, z;
+    xcd_remap(bx, by, z);  // an XCD works on a contiguous band of rows: the R1 rows a tile gathers stay in its L2
+    const int x = bx * 64 + (threadIdx.x & 63);
+    const int y = by * 4 + (threadIdx.x >> 6);
     if (x >= a.w || y >= a.h) return;
     const long long o = (long long)y * a.ld + x;
-    const int z = blockIdx.z;
     const float* __restrict__ R0 = a.R + (long long)(2 * z) * 5 * a.ps;
     const float* __restrict__ R1 = R0 + 5 * a.ps;
     float* __restrict__ flow = a.flow + (long long)z * 2 * a.fps;
@@ -740,7 +741,7 @@ __global__ __launch_bounds__(256) void tw_update_matrices(UpdArgs a)
 }
 
 // =====================================================================================================
-// K7+K8 (+K6)  tw_blur_solve<MH,COLS,HALO> : FarnebackUpdateFlow_GaussianBlur (optflowgf.cpp).
+// K7+K8 (+K6)  tw_blur_solve* : FarnebackUpdateFlow_GaussianBlur (optflowgf.cpp).
 //   (2*MH+1)-tap window average of the 5 M planes (float, centre-out pair order, replicate borders),
 //   2x2 solve in double with the +1e-3 regulariser, and — fused — the FarnebackUpdateMatrices refresh of
 //   the same pixel into the other M buffer (the CPU code's stripe-wise refresh is equivalent to
@@ -765,338 +766,6 @@ struct BlurArgs {
     int m;       // runtime m for the generic kernel
     WinCoef c;
 };
-
-template <int MH, int COLS, int HALO>
-__global__ __launch_bounds__(COLS) void tw_blur_solve(BlurArgs a)
-{
-    constexpr int TW = COLS - 2 * HALO;
-    __shared__ __attribute__((aligned(16))) float sm[5][BS_TH][COLS];
-    const int tid = threadIdx.x;
-    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * BS_TH;
-    const WinCoef& c = a.c;
-    const int z = blockIdx.z;
-    const float* __restrict__ Min = a.Min + (long long)z * 5 * a.ps;
-    float* __restrict__ Mout = a.Mout + (long long)z * 5 * a.ps;
-    float* __restrict__ flow = a.flow + (long long)z * 2 * a.fps;
-    const float* __restrict__ R0 = a.R + (long long)(2 * z) * 5 * a.ps;
-    const float* __restrict__ R1 = R0 + 5 * a.ps;
-
-    // ---- vertical blur: one column per thread ----
-    {
-        const int x = clampi(x0 - HALO + tid, 0, a.w - 1);
-#pragma unroll 1
-        for (int ch = 0; ch < 5; ch++) {
-            const float* __restrict__ Mp = Min + ch * a.ps + x;
-            float win[BS_TH + 2 * MH];
-#pragma unroll
-            for (int i = 0; i < BS_TH + 2 * MH; i++) {
-                const int y = clampi(y0 - MH + i, 0, a.h - 1);
-                win[i] = Mp[(long long)y * a.ld];
-            }
-#pragma unroll
-            for (int r = 0; r < BS_TH; r++) {
-                float s0 = win[r + MH] * c.k[0];
-#pragma unroll
-                for (int i = 1; i <= MH; i++) s0 += (win[r + MH + i] + win[r + MH - i]) * c.k[i];
-                sm[ch][r][tid] = s0;
-            }
-        }
-    }
-    __syncthreads();
-
-    // ---- horizontal blur + solve (+ matrix refresh): items = 8 rows x TW/4 groups ----
-    constexpr int GROUPS = TW / 4;
-    constexpr int WL = 4 + 2 * HALO;
-    for (int it = tid; it < BS_TH * GROUPS; it += COLS) {
-        const int r = it / GROUPS, q = it - r * GROUPS;
-        const int y = y0 + r, x = x0 + 4 * q;
-        if (y >= a.h || x >= a.w) continue;
-        float hs[5][4];
-#pragma unroll
-        for (int ch = 0; ch < 5; ch++) {
-            float v[WL];
-#pragma unroll
-            for (int u = 0; u < WL / 4; u++) {
-                const f32x4 A = *(const f32x4*)&sm[ch][r][4 * q + 4 * u];
-                v[4 * u] = A[0];
-                v[4 * u + 1] = A[1];
-                v[4 * u + 2] = A[2];
-                v[4 * u + 3] = A[3];
-            }
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int li = HALO + j;
-                float sum = v[li] * c.k[0];
-#pragma unroll
-                for (int i = 1; i <= MH; i++) sum += c.k[i] * (v[li - i] + v[li + i]);
-                hs[ch][j] = sum;
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            if (x + j >= a.w) break;
-            const double g11 = hs[0][j], g12 = hs[1][j], g22 = hs[2][j], h1 = hs[3][j], h2 = hs[4][j];
-            const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
-            const float fxv = (float)((g11 * h2 - g12 * h1) * idet);
-            const float fyv = (float)((g22 * h1 - g12 * h2) * idet);
-            const long long o = (long long)y * a.ld + x + j;
-            flow[o] = fxv;
-            flow[o + a.fps] = fyv;
-            if (a.update) {
-                float M[5];
-                update_matrices_px(R0, R1, a.ps, a.ld, a.w, a.h, x + j, y, fxv, fyv, M);
-#pragma unroll
-                for (int cc = 0; cc < 5; cc++) Mout[o + cc * a.ps] = M[cc];
-            }
-        }
-    }
-}
-
-// -----------------------------------------------------------------------------------------------------
-// tw_blur_solve2<MH,COLS,HALO,TH,MINW> : the same arithmetic, tuned issue stream.
-//   * no fused matrix refresh (the refresh is a separate, high-occupancy gather kernel)
-//   * row bases are wave-uniform (SGPR) and the column is a 32-bit VGPR offset: loads need no VALU address math
-//   * TH rows per tile (9 divides 1080/540/270/135 and fills 504 of 512 horizontal work items)
-//   * __launch_bounds__(COLS, MINW) keeps the register budget at MINW waves per SIMD
-// -----------------------------------------------------------------------------------------------------
-template <int MH, int COLS, int HALO, int TH, int MINW>
-__global__ __launch_bounds__(COLS, MINW) void tw_blur_solve2(BlurArgs a)
-{
-    constexpr int TW = COLS - 2 * HALO;
-    __shared__ __attribute__((aligned(16))) float sm[5][TH][COLS];
-    const int tid = threadIdx.x;
-    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
-    const WinCoef& c = a.c;
-    const int z = blockIdx.z;
-    const float* __restrict__ Min = a.Min + (long long)z * 5 * a.ps;
-    float* __restrict__ flow = a.flow + (long long)z * 2 * a.fps;
-
-    // ---- vertical blur: one column per thread, rows y0-MH .. y0+TH-1+MH in a register window ----
-    {
-        const unsigned xb = (unsigned)clampi(x0 - HALO + tid, 0, a.w - 1) * 4u;
-        const bool interior = (y0 - MH >= 0) && (y0 + TH - 1 + MH <= a.h - 1);  // wave-uniform
-        const __amdgpu_buffer_rsrc_t rsM = make_rsrc(Min);
-        const unsigned ldb = (unsigned)a.ld * 4u, psb = (unsigned)(a.ps * 4);
-#pragma unroll 1
-        for (int ch = 0; ch < 5; ch++) {
-            float win[TH + 2 * MH];
-            if (interior) {
-                unsigned so = ch * psb + (unsigned)(y0 - MH) * ldb;
-#pragma unroll
-                for (int i = 0; i < TH + 2 * MH; i++) {
-                    win[i] = bload(rsM, xb, so);
-                    so += ldb;
-                }
-            } else {
-                int yy = y0 - MH;
-                unsigned so = ch * psb + (unsigned)clampi(yy, 0, a.h - 1) * ldb;
-#pragma unroll
-                for (int i = 0; i < TH + 2 * MH; i++) {
-                    win[i] = bload(rsM, xb, so);
-                    yy++;
-                    so += (yy > 0 && yy < a.h) ? ldb : 0u;  // replicate rows outside the image
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < TH; r++) {
-                float s0 = win[r + MH] * c.k[0];
-#pragma unroll
-                for (int i = 1; i <= MH; i++) s0 += (win[r + MH + i] + win[r + MH - i]) * c.k[i];
-                sm[ch][r][tid] = s0;
-                // rows are issued in order, two at a time: without this the scheduler interleaves all TH rows
-                // and keeps ~120 temporaries live (124 VGPRs instead of ~50 for this phase)
-                if (r & 1) __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-    }
-    __syncthreads();
-
-    // ---- horizontal blur + solve: items = TH rows x TW/4 groups of 4 pixels ----
-    constexpr int GROUPS = TW / 4;
-    constexpr int WL = 4 + 2 * HALO;
-#pragma unroll 1
-    for (int it = tid; it < TH * GROUPS; it += COLS) {
-        const int r = it / GROUPS, q = it - r * GROUPS;
-        const int y = y0 + r, x = x0 + 4 * q;
-        if (y >= a.h || x >= a.w) continue;
-        float hs[5][4];
-#pragma unroll
-        for (int ch = 0; ch < 5; ch++) {
-            float v[WL];
-#pragma unroll
-            for (int u = 0; u < WL / 4; u++) {
-                const f32x4 A = *(const f32x4*)&sm[ch][r][4 * q + 4 * u];
-                v[4 * u] = A[0];
-                v[4 * u + 1] = A[1];
-                v[4 * u + 2] = A[2];
-                v[4 * u + 3] = A[3];
-            }
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int li = HALO + j;
-                float sum = v[li] * c.k[0];
-#pragma unroll
-                for (int i = 1; i <= MH; i++) sum += c.k[i] * (v[li - i] + v[li + i]);
-                hs[ch][j] = sum;
-                if (j & 1) __builtin_amdgcn_sched_barrier(0);  // two pixels in flight, one channel window live
-            }
-        }
-        float fxv[4], fyv[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const double g11 = hs[0][j], g12 = hs[1][j], g22 = hs[2][j], h1 = hs[3][j], h2 = hs[4][j];
-            const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
-            fxv[j] = (float)((g11 * h2 - g12 * h1) * idet);
-            fyv[j] = (float)((g22 * h1 - g12 * h2) * idet);
-        }
-        float* fo = flow + (long long)y * a.ld + x;
-        if (x + 3 < a.w) {
-            *(f32x4*)fo = f32x4{fxv[0], fxv[1], fxv[2], fxv[3]};
-            *(f32x4*)(fo + a.fps) = f32x4{fyv[0], fyv[1], fyv[2], fyv[3]};
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-                if (x + j < a.w) {
-                    fo[j] = fxv[j];
-                    fo[j + a.fps] = fyv[j];
-                }
-        }
-    }
-}
-
-// -----------------------------------------------------------------------------------------------------
-// tw_blur_solve3<MH,COLS,HALO,TH,FUSED> : low-register-pressure structure (4 workgroups = 16 waves per CU).
-//   V  : vertical blur of the 5 planes, one column per thread, register window, raw buffer loads  -> LDS
-//   H  : per plane: every work item reads its 4+2*HALO window from LDS and forms 4 blurred pixels in
-//        registers; after a barrier the results overwrite the (no longer needed) vertical sums in place
-//   S  : one pixel per lane (lane-consecutive x: coalesced stores and gathers): 2x2 solve in double,
-//        flow store, and — FUSED — the FarnebackUpdateMatrices refresh of that pixel into Mout
-// -----------------------------------------------------------------------------------------------------
-template <int MH, int COLS, int HALO, int TH, bool FUSED>
-__global__ __launch_bounds__(COLS) void tw_blur_solve3(BlurArgs a)
-{
-    constexpr int TW = COLS - 2 * HALO;
-    __shared__ __attribute__((aligned(16))) float sm[5][TH][COLS];
-    const int tid = threadIdx.x;
-    int bx, by, z;
-    xcd_remap(bx, by, z);
-    const int x0 = bx * TW, y0 = by * TH;
-    const WinCoef& c = a.c;
-    const float* __restrict__ Min = a.Min + (long long)z * 5 * a.ps;
-    float* __restrict__ flow = a.flow + (long long)z * 2 * a.fps;
-
-    // ---- V: vertical blur, rows y0-MH .. y0+TH-1+MH of the thread's column in a register window ----
-    {
-        const unsigned xb = (unsigned)clampi(x0 - HALO + tid, 0, a.w - 1) * 4u;
-        const bool interior = (y0 - MH >= 0) && (y0 + TH - 1 + MH <= a.h - 1);  // wave-uniform
-        const __amdgpu_buffer_rsrc_t rsM = make_rsrc(Min);
-        const unsigned ldb = (unsigned)a.ld * 4u, psb = (unsigned)(a.ps * 4);
-#pragma unroll 1
-        for (int ch = 0; ch < 5; ch++) {
-            float win[TH + 2 * MH];
-            if (interior) {
-                unsigned so = ch * psb + (unsigned)(y0 - MH) * ldb;
-#pragma unroll
-                for (int i = 0; i < TH + 2 * MH; i++) {
-                    win[i] = bload(rsM, xb, so);
-                    so += ldb;
-                }
-            } else {
-                int yy = y0 - MH;
-                unsigned so = ch * psb + (unsigned)clampi(yy, 0, a.h - 1) * ldb;
-#pragma unroll
-                for (int i = 0; i < TH + 2 * MH; i++) {
-                    win[i] = bload(rsM, xb, so);
-                    yy++;
-                    so += (yy > 0 && yy < a.h) ? ldb : 0u;  // replicate rows outside the image
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < TH; r++) {
-                float s0 = win[r + MH] * c.k[0];
-#pragma unroll
-                for (int i = 1; i <= MH; i++) s0 += (win[r + MH + i] + win[r + MH - i]) * c.k[i];
-                sm[ch][r][tid] = s0;
-                // rows are issued in order, two at a time (otherwise all TH rows are interleaved and ~120
-                // temporaries stay live)
-                if (r & 1) __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-    }
-    __syncthreads();
-
-    // ---- H: horizontal blur, in place ----
-    constexpr int GROUPS = TW / 4;
-    constexpr int NITEM = TH * GROUPS;
-    constexpr int ROUNDS = (NITEM + COLS - 1) / COLS;
-    constexpr int WL = 4 + 2 * HALO;
-#pragma unroll 1
-    for (int ch = 0; ch < 5; ch++) {
-        f32x4 res[ROUNDS];
-#pragma unroll
-        for (int rd = 0; rd < ROUNDS; rd++) {
-            const int it = tid + rd * COLS;
-            if (it < NITEM) {
-                const int r = it / GROUPS, q = it - r * GROUPS;
-                float v[WL];
-#pragma unroll
-                for (int u = 0; u < WL / 4; u++) {
-                    const f32x4 A = *(const f32x4*)&sm[ch][r][4 * q + 4 * u];
-                    v[4 * u] = A[0];
-                    v[4 * u + 1] = A[1];
-                    v[4 * u + 2] = A[2];
-                    v[4 * u + 3] = A[3];
-                }
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const int li = HALO + j;
-                    float sum = v[li] * c.k[0];
-#pragma unroll
-                    for (int i = 1; i <= MH; i++) sum += c.k[i] * (v[li - i] + v[li + i]);
-                    res[rd][j] = sum;
-                    if (j & 1) __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-        }
-        __syncthreads();  // every window of this plane has been read: its interior may be overwritten
-#pragma unroll
-        for (int rd = 0; rd < ROUNDS; rd++) {
-            const int it = tid + rd * COLS;
-            if (it < NITEM) {
-                const int r = it / GROUPS, q = it - r * GROUPS;
-                *(f32x4*)&sm[ch][r][HALO + 4 * q] = res[rd];
-            }
-        }
-    }
-    __syncthreads();
-
-    // ---- S: solve (+ refresh), one pixel per lane ----
-    float* __restrict__ Mout = a.Mout + (long long)z * 5 * a.ps;
-    const float* __restrict__ R0 = a.R + (long long)(2 * z) * 5 * a.ps;
-    const float* __restrict__ R1 = R0 + 5 * a.ps;
-#pragma unroll 1
-    for (int p = tid; p < TH * TW; p += COLS) {
-        const int r = p / TW, cx = p - r * TW;
-        const int x = x0 + cx, y = y0 + r;
-        if (x >= a.w || y >= a.h) continue;
-        const double g11 = sm[0][r][HALO + cx], g12 = sm[1][r][HALO + cx], g22 = sm[2][r][HALO + cx],
-                     h1 = sm[3][r][HALO + cx], h2 = sm[4][r][HALO + cx];
-        const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
-        const float fxv = (float)((g11 * h2 - g12 * h1) * idet);
-        const float fyv = (float)((g22 * h1 - g12 * h2) * idet);
-        const long long o = (long long)y * a.ld + x;
-        flow[o] = fxv;
-        flow[o + a.fps] = fyv;
-        if (FUSED) {
-            if (a.update) {
-                float M[5];
-                update_matrices_px(R0, R1, a.ps, a.ld, a.w, a.h, x, y, fxv, fyv, M);
-#pragma unroll
-                for (int cc = 0; cc < 5; cc++) Mout[o + cc * a.ps] = M[cc];
-            }
-        }
-    }
-}
 
 // -----------------------------------------------------------------------------------------------------
 // tw_blur_solve4<MH,COLS,HALO,TH,FUSED> : v3 with the stalls taken out.
@@ -1229,367 +898,6 @@ __global__ __launch_bounds__(COLS) void tw_blur_solve4(BlurArgs a)
 }
 
 // -----------------------------------------------------------------------------------------------------
-// tw_blur_solve5<MH,COLS,HALO,TH> : wave-specialised fused kernel for the iterations that refresh M.
-//   The blur of a tile is VALU-bound, the solve + UpdateMatrices refresh of a tile is HBM/gather-bound; run one
-//   after the other they add up (v4).  Here a 2*COLS-thread workgroup walks a strip of tiles with two roles:
-//     waves 0..COLS/64-1  ("blur")    : vertical + horizontal window average of tile t   -> LDS buffer t&1
-//     waves COLS/64..     ("refresh") : 2x2 solve, flow store and M refresh of tile t-1  <- LDS buffer (t-1)&1
-//   so the memory-bound half of tile t-1 overlaps the compute-bound half of tile t on the same CU.  Both roles
-//   meet at the three workgroup barriers of a step (gfx950 has no named barriers); the refresh role splits its
-//   pixels 4 : 3 over the first two segments.  Arithmetic and order are those of v4 (bit-identical results).
-// -----------------------------------------------------------------------------------------------------
-template <int MH, int COLS, int HALO, int TH>
-__global__ __launch_bounds__(2 * COLS) void tw_blur_solve5(BlurArgs a, int tps /*tiles per strip*/)
-{
-    constexpr int TW = COLS - 2 * HALO;
-    constexpr int NW = TH + 2 * MH;
-    constexpr int PX = TH * TW / COLS;  // pixels per lane in the refresh role
-    static_assert((TH * TW) % COLS == 0, "pixels per lane must be whole");
-    __shared__ __attribute__((aligned(16))) float sm[2][5][TH][COLS];
-    const int role = threadIdx.x / COLS;  // wave-uniform
-    const int tid = threadIdx.x - role * COLS;
-    const WinCoef& c = a.c;
-    const int ntx = (a.w + TW - 1) / TW, nty = (a.h + TH - 1) / TH;
-    const int tiles_per_pair = ntx * nty;
-    const int strips_per_pair = (tiles_per_pair + tps - 1) / tps;
-    // XCD-aware linear workgroup id -> (pair, strip)
-    int bid;
-    {
-        const unsigned n = gridDim.x;
-        unsigned b = blockIdx.x;
-        const unsigned xcd = b & 7u, q = n >> 3, r = n & 7u;
-        bid = (int)((xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3));
-    }
-    const int z = bid / strips_per_pair;
-    const int t0 = (bid - z * strips_per_pair) * tps;
-    const int nt = min(tps, tiles_per_pair - t0);
-    const float* __restrict__ Min = a.Min + (long long)z * 5 * a.ps;
-    float* __restrict__ Mout = a.Mout + (long long)z * 5 * a.ps;
-    float* __restrict__ flow = a.flow + (long long)z * 2 * a.fps;
-    const float* __restrict__ R0 = a.R + (long long)(2 * z) * 5 * a.ps;
-    const float* __restrict__ R1 = R0 + 5 * a.ps;
-
-    constexpr int GROUPS = TW / 4;
-    constexpr int NITEM = TH * GROUPS;
-    constexpr int ROUNDS = (NITEM + COLS - 1) / COLS;
-    constexpr int WL = 4 + 2 * HALO;
-
-    // solve (+ refresh) of pixels [p0, p1) of this lane in tile (x0,y0), blurred sums in sm[buf]
-    auto refresh_px = [&](int buf, int x0, int y0, int p0, int p1) {
-#pragma unroll 2
-        for (int pi = p0; pi < p1; pi++) {
-            const int p = tid + pi * COLS;
-            const int r = p / TW, cx = p - r * TW;
-            const int x = x0 + cx, y = y0 + r;
-            if (x >= a.w || y >= a.h) continue;
-            const double g11 = sm[buf][0][r][HALO + cx], g12 = sm[buf][1][r][HALO + cx], g22 = sm[buf][2][r][HALO + cx],
-                         h1 = sm[buf][3][r][HALO + cx], h2 = sm[buf][4][r][HALO + cx];
-            const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
-            const float fxv = (float)((g11 * h2 - g12 * h1) * idet);
-            const float fyv = (float)((g22 * h1 - g12 * h2) * idet);
-            const long long o = (long long)y * a.ld + x;
-            flow[o] = fxv;
-            flow[o + a.fps] = fyv;
-            if (a.update) {
-                float M[5];
-                update_matrices_px(R0, R1, a.ps, a.ld, a.w, a.h, x, y, fxv, fyv, M);
-#pragma unroll
-                for (int cc = 0; cc < 5; cc++) Mout[o + cc * a.ps] = M[cc];
-            }
-        }
-    };
-
-    // Each role runs its own loop; both execute exactly 3 workgroup barriers per step for nt+1 steps (the
-    // hardware barrier counts arrivals, the two roles never need to be at the same program counter).
-    if (role == 0) {
-        // ================= blur role: tile `step` -> sm[step&1] =================
-        for (int step = 0; step <= nt; step++) {
-            const int buf = step & 1;
-            const bool on = step < nt;
-            const int tb = t0 + min(step, nt - 1);
-            const int x0 = (tb % ntx) * TW, y0 = (tb / ntx) * TH;
-            f32x4 res[ROUNDS][5];
-            if (on) {
-                const unsigned xb = (unsigned)clampi(x0 - HALO + tid, 0, a.w - 1) * 4u;
-                unsigned ro[NW];
-#pragma unroll
-                for (int i = 0; i < NW; i++) ro[i] = (unsigned)clampi(y0 - MH + i, 0, a.h - 1) * ((unsigned)a.ld * 4u);
-                float wa[NW], wb[NW];
-                {
-                    const __amdgpu_buffer_rsrc_t rs = make_rsrc(Min);
-#pragma unroll
-                    for (int i = 0; i < NW; i++) wa[i] = bload(rs, xb, ro[i]);
-                }
-#pragma unroll
-                for (int ch = 0; ch < 5; ch++) {
-                    float* cur = (ch & 1) ? wb : wa;
-                    float* nxt = (ch & 1) ? wa : wb;
-                    if (ch < 4) {
-                        const __amdgpu_buffer_rsrc_t rs = make_rsrc(Min + (long long)(ch + 1) * a.ps);
-#pragma unroll
-                        for (int i = 0; i < NW; i++) nxt[i] = bload(rs, xb, ro[i]);
-                    }
-#pragma unroll
-                    for (int r = 0; r < TH; r++) {
-                        float s0 = cur[r + MH] * c.k[0];
-#pragma unroll
-                        for (int i = 1; i <= MH; i++) s0 += (cur[r + MH + i] + cur[r + MH - i]) * c.k[i];
-                        sm[buf][ch][r][tid] = s0;
-                        if (r & 1) __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
-            }
-            __syncthreads();
-            if (on) {
-#pragma unroll
-                for (int rd = 0; rd < ROUNDS; rd++) {
-                    const int it = tid + rd * COLS;
-                    // IR-level fence: without it the LDS reads of the next round are speculated above this
-                    // round (45 x 16 B live = 180 VGPRs)
-                    asm volatile("" ::: "memory");
-                    if (it < NITEM) {
-                        const int r = it / GROUPS, q = it - r * GROUPS;
-#pragma unroll
-                        for (int ch = 0; ch < 5; ch++) {
-                            float v[WL];
-#pragma unroll
-                            for (int u = 0; u < WL / 4; u++) {
-                                const f32x4 A = *(const f32x4*)&sm[buf][ch][r][4 * q + 4 * u];
-                                v[4 * u] = A[0];
-                                v[4 * u + 1] = A[1];
-                                v[4 * u + 2] = A[2];
-                                v[4 * u + 3] = A[3];
-                            }
-#pragma unroll
-                            for (int j = 0; j < 4; j++) {
-                                const int li = HALO + j;
-                                float sum = v[li] * c.k[0];
-#pragma unroll
-                                for (int i = 1; i <= MH; i++) sum += c.k[i] * (v[li - i] + v[li + i]);
-                                res[rd][ch][j] = sum;
-                                if (j & 1) __builtin_amdgcn_sched_barrier(0);
-                            }
-                            // pin this plane's results here: otherwise the whole round is sunk below the next
-                            // round and its 45 window loads stay live (180 VGPRs)
-                            asm volatile("" : "+v"(res[rd][ch]));
-                        }
-                    }
-                }
-            }
-            __syncthreads();
-            if (on) {
-#pragma unroll
-                for (int rd = 0; rd < ROUNDS; rd++) {
-                    const int it = tid + rd * COLS;
-                    if (it < NITEM) {
-                        const int r = it / GROUPS, q = it - r * GROUPS;
-#pragma unroll
-                        for (int ch = 0; ch < 5; ch++) *(f32x4*)&sm[buf][ch][r][HALO + 4 * q] = res[rd][ch];
-                    }
-                }
-            }
-            __syncthreads();
-        }
-    } else {
-        // ================= refresh role: tile `step-1` <- sm[(step-1)&1] =================
-        for (int step = 0; step <= nt; step++) {
-            const int buf = (step & 1) ^ 1;
-            const int tr = t0 + max(step - 1, 0);
-            const int rx0 = (tr % ntx) * TW, ry0 = (tr / ntx) * TH;
-            if (step >= 1) refresh_px(buf, rx0, ry0, 0, (PX + 1) / 2);
-            __syncthreads();
-            if (step >= 1) refresh_px(buf, rx0, ry0, (PX + 1) / 2, PX);
-            __syncthreads();
-            __syncthreads();
-        }
-    }
-}
-
-// -----------------------------------------------------------------------------------------------------
-// tw_blur_solve6<MH,COLS,HALO,TH,FUSED> : packed-f32 version of v4.
-//   On gfx950 every wave64 VALU instruction occupies its SIMD for ~4.3 cycles — v_pk_add_f32 / v_pk_mul_f32
-//   included (tools/ubench/valu_rate.hip, valu_dep.hip) — so two independent pixels per instruction halve the
-//   cost of the window average, which is pure non-fusable add/mul work (v4 already runs the VALU ~100 % busy).
-//   Pairs are chosen so that operands are naturally even-aligned register pairs (no shuffles):
-//     V : a lane owns two adjacent COLUMNS (8-byte loads);  s{x,x+1} += (w[a]{x,x+1} + w[b]{x,x+1}) * k
-//     H : an item owns 4 pixels of two adjacent ROWS; LDS holds float2 {row 2p, row 2p+1} per column
-//     S : a lane solves the two vertically adjacent pixels of a column (lane-consecutive x)
-//   IEEE add/mul per component, same order as the CPU code: results stay bit-identical.
-//   COLS/2 threads per workgroup, 40 KB LDS -> 4 workgroups (8 waves) per CU; the VGPR budget of 2 waves per
-//   SIMD pays for two prefetched register windows.
-// -----------------------------------------------------------------------------------------------------
-template <int MH, int COLS, int HALO, int TH, bool FUSED>
-__global__ __launch_bounds__(COLS / 2) void tw_blur_solve6(BlurArgs a)
-{
-    constexpr int NT = COLS / 2;          // threads
-    constexpr int TW = COLS - 2 * HALO;   // output columns
-    constexpr int NW = TH + 2 * MH;       // window rows
-    constexpr int RP = TH / 2;            // row pairs
-    static_assert(TH % 4 == 0 && HALO % 4 == 0 && TW % 4 == 0, "tile shape");
-    __shared__ __attribute__((aligned(16))) f32x2 sm[5][RP][COLS];  // {row 2p, row 2p+1} per column
-    const int tid = threadIdx.x;
-    int bx, by, z;
-    xcd_remap(bx, by, z);
-    const int x0 = bx * TW, y0 = by * TH;
-    const WinCoef& c = a.c;
-    const float* __restrict__ Min = a.Min + (long long)z * 5 * a.ps;
-    float* __restrict__ flow = a.flow + (long long)z * 2 * a.fps;
-
-    // ---- V: two adjacent columns per lane ----
-    {
-        const int c0 = 2 * tid;
-        const int xg = x0 - HALO + c0;
-        const bool pair_ok = (xg >= 0) && (xg + 1 <= a.w - 1);
-        const bool all_ok = __all(pair_ok);  // wave-uniform: 8-byte loads for the whole wave
-        const unsigned xb0 = (unsigned)clampi(xg, 0, a.w - 1) * 4u, xb1 = (unsigned)clampi(xg + 1, 0, a.w - 1) * 4u;
-        unsigned ro[NW];
-#pragma unroll
-        for (int i = 0; i < NW; i++) ro[i] = (unsigned)clampi(y0 - MH + i, 0, a.h - 1) * ((unsigned)a.ld * 4u);
-        f32x2 wa[NW], wb[NW];
-        auto load_plane = [&](int ch, f32x2* w) {
-            const __amdgpu_buffer_rsrc_t rs = make_rsrc(Min + (long long)ch * a.ps);
-            if (all_ok) {
-#pragma unroll
-                for (int i = 0; i < NW; i++) w[i] = bload2(rs, xb0, ro[i]);
-            } else {
-#pragma unroll
-                for (int i = 0; i < NW; i++) {
-                    w[i].x = bload(rs, xb0, ro[i]);
-                    w[i].y = bload(rs, xb1, ro[i]);
-                }
-            }
-        };
-        load_plane(0, wa);
-#pragma unroll
-        for (int ch = 0; ch < 5; ch++) {
-            f32x2* cur = (ch & 1) ? wb : wa;
-            f32x2* nxt = (ch & 1) ? wa : wb;
-            if (ch < 4) load_plane(ch + 1, nxt);
-#pragma unroll
-            for (int rp = 0; rp < RP; rp += 2) {
-                // four output rows advance in lockstep: independent chains between dependent packed ops
-                // (a dependent v_pk pair otherwise costs an s_nop each)
-                f32x2 s[4];
-#pragma unroll
-                for (int q = 0; q < 4; q++) s[q] = cur[2 * rp + q + MH] * c.k[0];
-#pragma unroll
-                for (int i = 1; i <= MH; i++) {
-                    f32x2 t[4];
-#pragma unroll
-                    for (int q = 0; q < 4; q++) t[q] = cur[2 * rp + q + MH + i] + cur[2 * rp + q + MH - i];
-#pragma unroll
-                    for (int q = 0; q < 4; q++) t[q] = t[q] * c.k[i];
-#pragma unroll
-                    for (int q = 0; q < 4; q++) s[q] += t[q];
-                }
-                *(f32x4*)&sm[ch][rp][c0] = f32x4{s[0].x, s[1].x, s[0].y, s[1].y};
-                *(f32x4*)&sm[ch][rp + 1][c0] = f32x4{s[2].x, s[3].x, s[2].y, s[3].y};
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-    }
-    __syncthreads();
-
-    // ---- H: 4 pixels x 2 rows per item, all planes, results in registers ----
-    constexpr int GROUPS = TW / 4;
-    constexpr int NITEM = RP * GROUPS;
-    constexpr int ROUNDS = (NITEM + NT - 1) / NT;
-    constexpr int WL = 4 + 2 * HALO;
-    f32x2 res[ROUNDS][5][4];
-#pragma unroll
-    for (int rd = 0; rd < ROUNDS; rd++) {
-        const int it = tid + rd * NT;
-        if (it < NITEM) {
-            const int rp = it / GROUPS, q = it - rp * GROUPS;
-#pragma unroll
-            for (int ch = 0; ch < 5; ch++) {
-                f32x2 v[WL];
-#pragma unroll
-                for (int u = 0; u < WL / 2; u++) {
-                    const f32x4 A = *(const f32x4*)&sm[ch][rp][4 * q + 2 * u];
-                    v[2 * u] = f32x2{A[0], A[1]};
-                    v[2 * u + 1] = f32x2{A[2], A[3]};
-                }
-                {
-                    f32x2 sum[4];
-#pragma unroll
-                    for (int j = 0; j < 4; j++) sum[j] = v[HALO + j] * c.k[0];
-#pragma unroll
-                    for (int i = 1; i <= MH; i++) {
-                        f32x2 t[4];
-#pragma unroll
-                        for (int j = 0; j < 4; j++) t[j] = v[HALO + j - i] + v[HALO + j + i];
-#pragma unroll
-                        for (int j = 0; j < 4; j++) t[j] = c.k[i] * t[j];
-#pragma unroll
-                        for (int j = 0; j < 4; j++) sum[j] += t[j];
-                    }
-#pragma unroll
-                    for (int j = 0; j < 4; j++) res[rd][ch][j] = sum[j];
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-            // pin: keeps this round from being sunk below the next one (its windows would stay live)
-#pragma unroll
-            for (int ch = 0; ch < 5; ch++)
-#pragma unroll
-                for (int j = 0; j < 4; j++) asm volatile("" : "+v"(res[rd][ch][j]));
-        }
-    }
-    __syncthreads();  // every window has been read: the interiors may be overwritten
-#pragma unroll
-    for (int rd = 0; rd < ROUNDS; rd++) {
-        const int it = tid + rd * NT;
-        if (it < NITEM) {
-            const int rp = it / GROUPS, q = it - rp * GROUPS;
-#pragma unroll
-            for (int ch = 0; ch < 5; ch++) {
-                *(f32x4*)&sm[ch][rp][HALO + 4 * q] =
-                    f32x4{res[rd][ch][0].x, res[rd][ch][0].y, res[rd][ch][1].x, res[rd][ch][1].y};
-                *(f32x4*)&sm[ch][rp][HALO + 4 * q + 2] =
-                    f32x4{res[rd][ch][2].x, res[rd][ch][2].y, res[rd][ch][3].x, res[rd][ch][3].y};
-            }
-        }
-    }
-    __syncthreads();
-
-    // ---- S: solve (+ refresh): a lane takes the two vertically adjacent pixels of a column ----
-    float* __restrict__ Mout = a.Mout + (long long)z * 5 * a.ps;
-    const float* __restrict__ R0 = a.R + (long long)(2 * z) * 5 * a.ps;
-    const float* __restrict__ R1 = R0 + 5 * a.ps;
-    static_assert((RP * TW) % NT == 0, "column pairs per lane must be whole");
-#pragma unroll 1
-    for (int p = tid; p < RP * TW; p += NT) {
-        const int rp = p / TW, cx = p - rp * TW;
-        const int x = x0 + cx;
-        if (x >= a.w) continue;
-        f32x2 b[5];
-#pragma unroll
-        for (int ch = 0; ch < 5; ch++) b[ch] = sm[ch][rp][HALO + cx];
-#pragma unroll
-        for (int q = 0; q < 2; q++) {
-            const int y = y0 + 2 * rp + q;
-            if (y >= a.h) break;
-            const double g11 = b[0][q], g12 = b[1][q], g22 = b[2][q], h1 = b[3][q], h2 = b[4][q];
-            const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
-            const float fxv = (float)((g11 * h2 - g12 * h1) * idet);
-            const float fyv = (float)((g22 * h1 - g12 * h2) * idet);
-            const long long o = (long long)y * a.ld + x;
-            flow[o] = fxv;
-            flow[o + a.fps] = fyv;
-            if (FUSED) {
-                if (a.update) {
-                    float M[5];
-                    update_matrices_px(R0, R1, a.ps, a.ld, a.w, a.h, x, y, fxv, fyv, M);
-#pragma unroll
-                    for (int cc = 0; cc < 5; cc++) Mout[o + cc * a.ps] = M[cc];
-                }
-            }
-        }
-    }
-}
-
-// -----------------------------------------------------------------------------------------------------
 // tw_blur_solve8<MH,COLS,HALO,TH,FUSED,PREFETCH> : v4's tiling and occupancy (COLS threads, 40 KB LDS, 4
 //   workgroups = 16 waves per CU) with packed f32 arithmetic (see v6 for why):
 //     V : one column per lane; output rows are produced in PAIRS (r, r+1): the window is held as even-aligned
@@ -1624,11 +932,6 @@ __global__ __launch_bounds__(COLS) void tw_blur_solve8(BlurArgs a)
         f32x2 wa[NP], wb[NP];
         auto load_plane = [&](int ch, f32x2* w) {
             const __amdgpu_buffer_rsrc_t rs = make_rsrc(Min + (long long)ch * a.ps);
-            if (a.m & 0x100) {  // timing experiment (tools/kbench.py only): no global loads
-#pragma unroll
-                for (int i = 0; i < NP; i++) w[i] = f32x2{(float)(i + tid + ch), (float)(i - tid)};
-                return;
-            }
 #pragma unroll
             for (int i = 0; i < NP; i++) {
                 w[i].x = bload(rs, xb, ro[2 * i]);
@@ -1734,7 +1037,6 @@ __global__ __launch_bounds__(COLS) void tw_blur_solve8(BlurArgs a)
     }
     __syncthreads();
 
-    if (a.m & 0x200) return;  // timing experiment: V + H only
     // ---- S: solve (+ refresh): a lane takes the two vertically adjacent pixels of a column ----
     float* __restrict__ Mout = a.Mout + (long long)z * 5 * a.ps;
     const float* __restrict__ R0 = a.R + (long long)(2 * z) * 5 * a.ps;

@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""HBM traffic per launch of the level-0 kernels from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE).
+
+usage: pmc_traffic.py <dir-FETCH_SIZE> <dir-WRITE_SIZE> <out.json> [out.md]
+Units and gfx950 corrections as MI355X_MICROARCH.md §HBM prescribes: both counters are in KiB; FETCH_SIZE counts
+128-B requests at 64 B, i.e. reads exactly half of a coalesced stream -> doubled; WRITE_SIZE is exact.
+Only the largest grid of each kernel (the level-0 launches of the 1080p bench) goes into the JSON."""
+import collections
+import csv
+import glob
+import json
+import sys
+
+NAMES = {"tw_blur_solve": "tw_blur_solve", "tw_polyexp": "tw_polyexp", "tw_update_matrices": "tw_update_matrices",
+         "tw_pyr_k3<0>": "tw_pyr_level", "tw_span_scan": "tw_span_scan"}
+
+
+def load(d, cname):
+    agg = collections.defaultdict(list)
+    for f in glob.glob(d + "/**/*_counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == cname:
+                k = (r["Kernel_Name"].replace("void ", "").replace("twk::", ""), int(r["Grid_Size"]))
+                agg[k].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in agg.items()}, {k: len(v) for k, v in agg.items()}
+
+
+def main():
+    fetch, nf = load(sys.argv[1], "FETCH_SIZE")
+    write, _ = load(sys.argv[2], "WRITE_SIZE")
+    rows = []
+    for k in fetch:
+        rd = fetch[k] * 1024 * 2
+        wr = write.get(k, 0.0) * 1024
+        rows.append((k[0], k[1], nf[k], rd, wr))
+    rows.sort(key=lambda r: -(r[3] + r[4]) * r[2])
+    out = {}
+    for prefix, name in NAMES.items():
+        cand = [r for r in rows if r[0].startswith(prefix)]
+        if cand:
+            big = max(cand, key=lambda r: r[1] if not prefix.startswith("tw_blur") else r[2] * 1e12 + r[1])
+            out[name] = round(big[3] + big[4])
+    json.dump(out, open(sys.argv[3], "w"), indent=1)
+    if len(sys.argv) > 4:
+        with open(sys.argv[4], "w") as f:
+            f.write("# HBM traffic per launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)\n\n")
+            f.write("FETCH_SIZE x 1024 x 2 (gfx950 half-count correction), WRITE_SIZE x 1024.\n\n")
+            f.write("| kernel | grid (threads) | launches | read MB | write MB | total MB |\n|---|---|---|---|---|---|\n")
+            for r in rows:
+                f.write("| `%s` | %d | %d | %.1f | %.1f | %.1f |\n" % (r[0][:70], r[1], r[2], r[3] / 1e6, r[4] / 1e6,
+                                                                   (r[3] + r[4]) / 1e6))
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
