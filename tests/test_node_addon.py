@@ -73,3 +73,32 @@ def test_reference_mocha_suite_in_node():
     r = subprocess.run(["node", "test_reference.js"], cwd=HOST, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "all 4 reference tests passed" in r.stdout
+
+
+@needs_node
+def test_cli_contract_without_gpu():
+    """commandline.js: usage on missing paths, JSON responses and the final report on stdout."""
+    r = subprocess.run(["node", "commandline.js"], cwd=HOST, capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "[USAGE]" in r.stderr
+    r = subprocess.run(["node", "commandline.js", "-threshold", "3", "-span", "20", "/nonexistent/a.png", "/nonexistent/b.png"],
+                       cwd=HOST, capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stderr
+    docs = json.loads("[" + r.stdout.replace("}\n{", "},{") + "]")
+    assert docs[0] == {"status": "ERROR", "reason": "Can't open /nonexistent/a.png"}
+    assert docs[-1] == {"request": 1, "data": 0, "error": 1}
+
+
+@needs_node
+@pytest.mark.gpu
+def test_cli_on_the_golden_pair():
+    """BASELINE config[0] shape: one pair through the CLI with explicit options -> the 24 golden vectors."""
+    tree = os.path.join(ROOT, "tests", "golden", "tree")
+    r = subprocess.run(["node", "commandline.js", "-threshold", "5", "-span", "10", "-pyrLevels", "3",
+                        os.path.join(tree, "expected", "scenario2", "capture2.png"),
+                        os.path.join(tree, "revision2", "scenario2", "capture2.png")],
+                       cwd=HOST, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    docs = json.loads("[" + r.stdout.replace("}\n{", "},{") + "]")
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "expected_responses.json")))["revision2_capture2"]
+    assert docs[0]["status"] == "SUSPICIOUS" and docs[0]["vector"] == gold["vector"]
+    assert docs[-1] == {"request": 1, "data": 1, "error": 0}
