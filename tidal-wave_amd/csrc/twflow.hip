@@ -278,6 +278,9 @@ struct tw_engine {
     PolyCoef pc;
     WinCoef wc;
     int win_m = 15;
+    int box = 0;           // flags without 256: box window (FarnebackUpdateFlow_Blur), scan kernels
+    double* Vd = nullptr;  // running column sums of the box window (5 double planes per pair of a chunk)
+    size_t Vd_cap = 0;
     int img_aligned4 = 0;  // every image pointer and the row stride of the batch being enqueued are 4-byte aligned
     int lanes = 1;         // TW_LANES=2: the two halves of a batch run on two streams (memory-bound kernels of one
                            // half overlap the VALU-bound blur of the other); per-kernel hipEvent durations then
@@ -318,6 +321,22 @@ namespace {
 
 size_t staged_image_bytes(int w, int h);
 
+// scoped device allocations (per-stage test entry points, slow paths)
+struct Tmp {
+    std::vector<void*> v;
+    ~Tmp()
+    {
+        for (void* p : v) (void)hipFree(p);
+    }
+    template <typename T>
+    T* alloc(size_t n)
+    {
+        void* p = nullptr;
+        if (hipMalloc(&p, n * sizeof(T) + 256) != hipSuccess) return nullptr;
+        v.push_back(p);
+        return (T*)p;
+    }
+};
 template <typename T>
 tw_status upload_vec(tw_engine* e, Plan* pl, const std::vector<T>& v, T** out)
 {
@@ -472,7 +491,7 @@ tw_status reserve_workspace(tw_engine* e, const Plan* pl, int span, bool need_im
     size_t need = 0;
     for (const LevelPlan& L : pl->lv) need = std::max(need, (size_t)L.ps * 2 * L.chunk);
     need *= e->lanes;  // one workspace per lane, carved from the same allocations
-    bool grow = need > e->ws_elems || e->flow.size() < pl->lv.size();
+    bool grow = need > e->ws_elems || e->flow.size() < pl->lv.size() || (e->box && need / 2 * 5 > e->Vd_cap);
     if (!grow)
         for (size_t k = 0; k < pl->lv.size(); k++) {
             const size_t fc = (size_t)pl->lv[k].ps * 2 * (k == 0 ? pl->lv[0].chunk * e->lanes : e->cap);
@@ -497,6 +516,13 @@ tw_status reserve_workspace(tw_engine* e, const Plan* pl, int span, bool need_im
         TW_HIP(e, hipMalloc((void**)&e->M[0], need / 2 * 5 * 4 + 256));
         TW_HIP(e, hipMalloc((void**)&e->M[1], need / 2 * 5 * 4 + 256));
         e->ws_elems = need;
+    }
+    if (e->box && need / 2 * 5 > e->Vd_cap) {
+        if (e->Vd) (void)hipFree(e->Vd);
+        e->Vd = nullptr;
+        e->Vd_cap = 0;
+        TW_HIP(e, hipMalloc((void**)&e->Vd, need / 2 * 5 * sizeof(double) + 256));
+        e->Vd_cap = need / 2 * 5;
     }
     if (e->flow.size() < pl->lv.size()) {
         e->flow.resize(pl->lv.size(), nullptr);
@@ -671,6 +697,47 @@ void launch_blur(tw_engine* e, hipStream_t st, int w, int h, int ld, long long p
     a.c = e->wc;
     const int gy = (h + BS_TH - 1) / BS_TH;
     const bool wide = w > 480;  // 224-column tiles; narrow levels use 96-column tiles (less edge waste)
+    if (e->box) {
+        // box window: sequential double running sums (two scan kernels) + the standard refresh kernel
+        double* V = e->Vd;
+        Tmp tmp;
+        if (level < 0) {  // per-stage test entry: no engine workspace
+            V = tmp.alloc<double>((size_t)ps * 5 * npairs);
+            if (!V) return;
+        }
+        BoxArgs b;
+        b.Min = Min;
+        b.V = V;
+        b.flow = flow;
+        b.w = w;
+        b.h = h;
+        b.ld = ld;
+        b.ps = ps;
+        b.fps = ps;
+        b.m = e->win_m;
+        b.scale = 1. / ((double)e->p.winSize * e->p.winSize);
+        {
+            ProfScope pscope(e, st, TW_K_BLUR_SOLVE, level);
+            hipLaunchKernelGGL(tw_box_vscan, dim3((w + 63) / 64, 5, npairs), dim3(64), 0, st, b);
+            hipLaunchKernelGGL(tw_box_hscan_solve, dim3((h + 11) / 12, 1, npairs), dim3(64), 0, st, b);
+        }
+        if (update) {
+            UpdArgs u;
+            memset(&u, 0, sizeof(u));
+            u.R = R;
+            u.flow = flow;
+            u.M = Mout;
+            u.w = w;
+            u.h = h;
+            u.ld = ld;
+            u.ps = ps;
+            u.fps = ps;
+            ProfScope pscope(e, st, TW_K_UPDATE_MATRICES, level);
+            hipLaunchKernelGGL(tw_update_matrices<false>, dim3((w + 63) / 64, (h + 3) / 4, npairs), dim3(256), 0, st, u);
+        }
+        if (level < 0) (void)hipStreamSynchronize(st);  // tmp is freed on return
+        return;
+    }
     ProfScope pscope(e, st, TW_K_BLUR_SOLVE, level);
     if (e->win_m == 15 && e->blur_variant == 8) {
         // packed-f32 structure (same speed as v4 at 1080p, lower VALU load); TW_BLUR_VARIANT=8 for A/B
@@ -990,7 +1057,6 @@ tw_status tw_engine_create(int device, const tw_params* params, int slots, tw_en
     if (!(p.pyrScale < 1) || !(p.pyrScale > 0)) return TW_E_UNSUPPORTED;  // CV_Assert(pyr_scale < 1)
     if (p.polyN < 1 || p.polyN > 7) return TW_E_UNSUPPORTED;
     if (p.winSize < 2 || p.winSize / 2 > 32) return TW_E_UNSUPPORTED;
-    if (!(p.flags & 256)) return TW_E_UNSUPPORTED;  // box window: not built yet
     if (p.pyrIterations < 0 || p.pyrLevels < 0) return TW_E_BAD_PARAMETER;
     if (slots < 1) slots = 1;
     if (slots > 256) slots = 256;
@@ -1004,6 +1070,7 @@ tw_status tw_engine_create(int device, const tw_params* params, int slots, tw_en
     polyexp_setup(p.polyN, p.polySigma, e->pc);
     window_kernel(p.winSize, e->wc);
     e->win_m = p.winSize / 2;
+    e->box = (p.flags & 256) ? 0 : 1;
     if (const char* ev = getenv("TW_BLUR_VARIANT")) e->blur_variant = atoi(ev);
     if (const char* ev = getenv("TW_PYR_GENERIC")) e->pyr_generic = atoi(ev);
     if (const char* ev = getenv("TW_LANES")) e->lanes = std::min(2, std::max(1, atoi(ev)));
@@ -1045,6 +1112,7 @@ void tw_engine_destroy(tw_engine* e)
     if (e->d_count) (void)hipFree(e->d_count);
     if (e->d_rec) (void)hipFree(e->d_rec);
     if (e->d_grid) (void)hipFree(e->d_grid);
+    if (e->Vd) (void)hipFree(e->Vd);
     for (Ctx& c : e->ctx) {
         if (c.h_img) (void)hipHostFree(c.h_img);
         if (c.h_ptrs) (void)hipHostFree((void*)c.h_ptrs);
@@ -1303,21 +1371,6 @@ double tw_algorithmic_bytes_pair(const tw_engine* e, int width, int height, int 
 
 // ---- per-stage entry points (tests) --------------------------------------------------------------------
 namespace {
-struct Tmp {
-    std::vector<void*> v;
-    ~Tmp()
-    {
-        for (void* p : v) (void)hipFree(p);
-    }
-    template <typename T>
-    T* alloc(size_t n)
-    {
-        void* p = nullptr;
-        if (hipMalloc(&p, n * sizeof(T) + 256) != hipSuccess) return nullptr;
-        v.push_back(p);
-        return (T*)p;
-    }
-};
 tw_status up_planes(tw_engine* e, float* d, int ld, long long ps, const float* h, int w, int hh, int planes)
 {
     for (int c = 0; c < planes; c++)

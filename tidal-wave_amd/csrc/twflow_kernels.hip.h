@@ -1128,6 +1128,69 @@ __global__ __launch_bounds__(256) void tw_blur_solve_generic(BlurArgs a)
 }
 
 // =====================================================================================================
+// FarnebackUpdateFlow_Blur (flags without OPTFLOW_FARNEBACK_GAUSSIAN): box window with DOUBLE running sums.
+//   The CPU code carries one running sum per column down the image and one per row across it; every step
+//   rounds, so bit-identical results need the same sequential order.  Two scan kernels (slow path, correct
+//   first): tw_box_vscan — one lane per column and plane walks the rows; tw_box_hscan_solve — five lanes per
+//   row (one per plane) walk the columns, the lane of plane 0 gathers the five sums with shuffles and solves.
+// =====================================================================================================
+struct BoxArgs {
+    const float* Min;  // pair z at + z*5*ps
+    double* V;         // pair z: 5 planes of running column sums at + z*5*ps
+    float* flow;       // pair z at + z*2*fps
+    int w, h, ld;
+    long long ps, fps;
+    int m;         // winSize / 2
+    double scale;  // 1 / winSize^2
+};
+
+__global__ __launch_bounds__(64) void tw_box_vscan(BoxArgs a)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x;
+    if (x >= a.w) return;
+    const int ch = blockIdx.y, z = blockIdx.z;
+    const float* __restrict__ M = a.Min + ((long long)z * 5 + ch) * a.ps + x;
+    double* __restrict__ V = a.V + ((long long)z * 5 + ch) * a.ps + x;
+    const int m = a.m, h = a.h;
+    double vs = (double)(M[0] * (float)(m + 2));  // srow0[x]*(m+2): float product
+    for (int y = 1; y < m; y++) vs += (double)M[(long long)min(y, h - 1) * a.ld];
+    for (int y = 0; y < h; y++) {
+        const float s1 = M[(long long)min(y + m, h - 1) * a.ld], s0 = M[(long long)max(y - m - 1, 0) * a.ld];
+        vs += (double)(s1 - s0);
+        V[(long long)y * a.ld] = vs;
+    }
+}
+
+__global__ __launch_bounds__(64) void tw_box_hscan_solve(BoxArgs a)
+{
+    const int lane = threadIdx.x;
+    const int rl = lane / 5, ch = lane - rl * 5;  // 12 rows x 5 planes per wave (lanes 60..63 idle)
+    const int y = blockIdx.x * 12 + rl;
+    const int z = blockIdx.z;
+    const bool on = (lane < 60) && (y < a.h);
+    const int yy = min(y, a.h - 1);
+    const double* __restrict__ V = a.V + ((long long)z * 5 + ch) * a.ps + (long long)yy * a.ld;
+    float* __restrict__ flow = a.flow + (long long)z * 2 * a.fps + (long long)yy * a.ld;
+    const int m = a.m, w = a.w;
+    // vsum has its first / last element replicated (m+1) times on either side
+    double g = V[0] * (double)(m + 2);
+    for (int x = 1; x < m; x++) g += V[min(x, w - 1)];
+    for (int x = 0; x < w; x++) {
+        g += V[min(x + m, w - 1)] - V[max(x - m - 1, 0)];
+        const double gs = g * a.scale;
+        // lanes 5r .. 5r+4 hold g11, g12, g22, h1, h2 of row r
+        const double g12 = __shfl(gs, lane + 1), g22 = __shfl(gs, lane + 2), h1 = __shfl(gs, lane + 3),
+                     h2 = __shfl(gs, lane + 4);
+        if (on && ch == 0) {
+            const double g11 = gs;
+            const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
+            flow[x] = (float)((g11 * h2 - g12 * h1) * idet);
+            flow[x + a.fps] = (float)((g22 * h1 - g12 * h2) * idet);
+        }
+    }
+}
+
+// =====================================================================================================
 // K12  the span-grid threshold scan of /root/reference/src/consumer.cpp:60-76, in two kernels:
 //   tw_span_gather : one thread per grid point copies (dx,dy) at (x*span, y*span) into a dense per-pair
 //                    buffer — fully parallel, launched per level-0 chunk while the flow is still in cache;
