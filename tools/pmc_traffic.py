@@ -34,12 +34,16 @@ def main():
         wr = write.get(k, 0.0) * 1024
         rows.append((k[0], k[1], nf[k], rd, wr))
     rows.sort(key=lambda r: -(r[3] + r[4]) * r[2])
+    # threads per PAIR of one level-0 launch at 1920x1080 (to turn a grid size into pairs per launch)
+    per_pair = {"tw_blur_solve": 9 * 135 * 256, "tw_polyexp": 2 * 8 * 135 * 256, "tw_update_matrices": 30 * 270 * 256,
+                "tw_pyr_level": 2 * 8 * 135 * 256, "tw_span_scan": 1024}
     out = {}
     for prefix, name in NAMES.items():
-        cand = [r for r in rows if r[0].startswith(prefix)]
+        cand = [r for r in rows if r[0].startswith(prefix) and r[1] % per_pair[name] == 0]
         if cand:
-            big = max(cand, key=lambda r: r[1] if not prefix.startswith("tw_blur") else r[2] * 1e12 + r[1])
-            out[name] = round(big[3] + big[4])
+            big = max(cand, key=lambda r: r[2])  # the most frequent level-0 launch shape
+            out[name] = {"bytes_per_launch": round(big[3] + big[4]), "pairs_per_launch": big[1] // per_pair[name],
+                         "read_bytes": round(big[3]), "write_bytes": round(big[4])}
     json.dump(out, open(sys.argv[3], "w"), indent=1)
     if len(sys.argv) > 4:
         with open(sys.argv[4], "w") as f:
