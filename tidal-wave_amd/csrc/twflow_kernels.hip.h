@@ -610,32 +610,40 @@ __device__ __forceinline__ void update_matrices_px(const float* __restrict__ R0,
     float r2, r3, r4, r5, r6;
     // (unsigned)x1 < (unsigned)(w-1) && (unsigned)y1 < (unsigned)(h-1), with cvFloor's INT_MIN for
     // out-of-range / NaN inputs: evaluated on the floats (exact: |.| < 2^24 inside the branch)
-    if (flx >= 0.f && flx < (float)(w - 1) && fly >= 0.f && fly < (float)(h - 1)) {
-        const int x1 = (int)flx, y1 = (int)fly;
-        fx -= (float)x1;
-        fy -= (float)y1;
-        const float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
-        const float* p = R1 + (long long)y1 * ld + x1;
-        r2 = a00 * p[0] + a01 * p[1] + a10 * p[ld] + a11 * p[ld + 1];
-        p += ps;
-        r3 = a00 * p[0] + a01 * p[1] + a10 * p[ld] + a11 * p[ld + 1];
-        p += ps;
-        r4 = a00 * p[0] + a01 * p[1] + a10 * p[ld] + a11 * p[ld + 1];
-        p += ps;
-        r5 = a00 * p[0] + a01 * p[1] + a10 * p[ld] + a11 * p[ld + 1];
-        p += ps;
-        r6 = a00 * p[0] + a01 * p[1] + a10 * p[ld] + a11 * p[ld + 1];
-        r4 = (R0[o + 2 * ps] + r4) * 0.5f;
-        r5 = (R0[o + 3 * ps] + r5) * 0.5f;
-        r6 = (R0[o + 4 * ps] + r6) * 0.25f;
+    const bool inb = flx >= 0.f && flx < (float)(w - 1) && fly >= 0.f && fly < (float)(h - 1);
+    // Branch-free: the 4x5 taps are always gathered (from a clamped, valid position) and discarded when the
+    // sample falls outside, so that the loads of several pixels can be in flight together.
+    const int x1 = inb ? (int)flx : 0, y1 = inb ? (int)fly : 0;
+    fx -= (float)x1;
+    fy -= (float)y1;
+    const float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
+    const float* p = R1 + (long long)y1 * ld + x1;
+    float t[5][4];
+#pragma unroll
+    for (int c = 0; c < 5; c++) {
+        t[c][0] = p[c * ps];
+        t[c][1] = p[c * ps + 1];
+        t[c][2] = p[c * ps + ld];
+        t[c][3] = p[c * ps + ld + 1];
+    }
+    const float q0 = R0[o], q1 = R0[o + ps], q2 = R0[o + 2 * ps], q3 = R0[o + 3 * ps], q4 = R0[o + 4 * ps];
+    if (inb) {
+        r2 = a00 * t[0][0] + a01 * t[0][1] + a10 * t[0][2] + a11 * t[0][3];
+        r3 = a00 * t[1][0] + a01 * t[1][1] + a10 * t[1][2] + a11 * t[1][3];
+        r4 = a00 * t[2][0] + a01 * t[2][1] + a10 * t[2][2] + a11 * t[2][3];
+        r5 = a00 * t[3][0] + a01 * t[3][1] + a10 * t[3][2] + a11 * t[3][3];
+        r6 = a00 * t[4][0] + a01 * t[4][1] + a10 * t[4][2] + a11 * t[4][3];
+        r4 = (q2 + r4) * 0.5f;
+        r5 = (q3 + r5) * 0.5f;
+        r6 = (q4 + r6) * 0.25f;
     } else {
         r2 = r3 = 0.f;
-        r4 = R0[o + 2 * ps];
-        r5 = R0[o + 3 * ps];
-        r6 = R0[o + 4 * ps] * 0.5f;
+        r4 = q2;
+        r5 = q3;
+        r6 = q4 * 0.5f;
     }
-    r2 = (R0[o] - r2) * 0.5f;
-    r3 = (R0[o + ps] - r3) * 0.5f;
+    r2 = (q0 - r2) * 0.5f;
+    r3 = (q1 - r3) * 0.5f;
     r2 += r4 * dy + r6 * dx;
     r3 += r6 * dy + r5 * dx;
     constexpr int BORDER = 5;
@@ -775,7 +783,7 @@ struct BlurArgs {
 //   * the horizontal results of all 5 planes stay in registers: 3 workgroup barriers instead of 7
 //   * solve / refresh phase handles two pixels per step (more gathers in flight per lane)
 // -----------------------------------------------------------------------------------------------------
-template <int MH, int COLS, int HALO, int TH, bool FUSED, int VILP = 2, int HILP = 2>
+template <int MH, int COLS, int HALO, int TH, bool FUSED, int VILP = 2, int HILP = 2, int SUNROLL = 2>
 __global__ __launch_bounds__(COLS) void tw_blur_solve4(BlurArgs a)
 {
     constexpr int TW = COLS - 2 * HALO;
@@ -873,25 +881,32 @@ __global__ __launch_bounds__(COLS) void tw_blur_solve4(BlurArgs a)
     const float* __restrict__ R0 = a.R + (long long)(2 * z) * 5 * a.ps;
     const float* __restrict__ R1 = R0 + 5 * a.ps;
     static_assert((TH * TW) % COLS == 0, "pixels per lane must be whole");
-#pragma unroll 2
+    // Every lane always computes (on a clamped, valid pixel); only the stores are predicated, so the loop body
+    // has no control flow and the gathers of SUNROLL pixels are in flight together.
+#pragma unroll SUNROLL
     for (int p = tid; p < TH * TW; p += COLS) {
         const int r = p / TW, cx = p - r * TW;
         const int x = x0 + cx, y = y0 + r;
-        if (x >= a.w || y >= a.h) continue;
+        const bool valid = x < a.w && y < a.h;
+        const int xc = min(x, a.w - 1), yc = min(y, a.h - 1);
         const double g11 = sm[0][r][HALO + cx], g12 = sm[1][r][HALO + cx], g22 = sm[2][r][HALO + cx],
                      h1 = sm[3][r][HALO + cx], h2 = sm[4][r][HALO + cx];
         const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
         const float fxv = (float)((g11 * h2 - g12 * h1) * idet);
         const float fyv = (float)((g22 * h1 - g12 * h2) * idet);
-        const long long o = (long long)y * a.ld + x;
-        flow[o] = fxv;
-        flow[o + a.fps] = fyv;
+        const long long o = (long long)yc * a.ld + xc;
+        if (valid) {
+            flow[o] = fxv;
+            flow[o + a.fps] = fyv;
+        }
         if (FUSED) {
-            if (a.update) {
+            if (a.update) {  // wave-uniform
                 float M[5];
-                update_matrices_px(R0, R1, a.ps, a.ld, a.w, a.h, x, y, fxv, fyv, M);
+                update_matrices_px(R0, R1, a.ps, a.ld, a.w, a.h, xc, yc, fxv, fyv, M);
+                if (valid) {
 #pragma unroll
-                for (int cc = 0; cc < 5; cc++) Mout[o + cc * a.ps] = M[cc];
+                    for (int cc = 0; cc < 5; cc++) Mout[o + cc * a.ps] = M[cc];
+                }
             }
         }
     }
