@@ -92,19 +92,26 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     dist = None
+    # one process per GPU; TW_BENCH_BACKEND=gloo lets two ranks share one card for a rehearsal on a 1-GPU box
+    backend = os.environ.get("TW_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if ndev < 1:
+        raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
+    dev_index = local_rank % ndev
+    torch.cuda.set_device(dev_index)
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(local_rank)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend=backend)
 
     import synth
     import twflow
 
     if twflow.device_count() < 1:
         raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
-    eng = twflow.Engine(local_rank, twflow.default_params(), slots=args.slots)
+    eng = twflow.Engine(dev_index, twflow.default_params(), slots=args.slots)
 
     # synthetic pairs: the same seeds on every rank (weak scaling: each rank owns its batch)
     host_pairs = [synth.make_pair(i, H, W) for i in range(args.distinct)]
@@ -149,7 +156,8 @@ def main():
     elapsed = time.perf_counter() - t0
     import shard
     elapsed, (flagged_total, pairs_total) = shard.reduce_max_sum(
-        dist, torch.device("cuda", local_rank), elapsed, [flagged[0], args.batch * args.steps])
+        dist, torch.device("cuda", dev_index) if backend == "nccl" else torch.device("cpu"), elapsed,
+        [flagged[0], args.batch * args.steps])
 
     prof = {}
     if not args.no_prof:
