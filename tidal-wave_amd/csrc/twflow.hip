@@ -218,6 +218,7 @@ struct LevelPlan {
     float *d_alpha = nullptr, *d_beta = nullptr, *d_kern = nullptr;
     int mode = 1, xmax = 0, nrows_max = 0;
     float h_kern[3] = {0, 0, 0};  // host copy of the taps when ksize == 3
+    std::vector<float> h_taps;    // host copy of all taps
     int pitch_b = 0;              // staged-row pitch (bytes) of tw_pyr_level_lds, 0: does not fit LDS
     // flow upsample tables (level k+1 -> k)
     int *d_uxofs = nullptr, *d_uyofs = nullptr;
@@ -287,7 +288,7 @@ struct tw_engine {
                            // include the co-running kernel
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    int pyr_generic = 0;   // TW_PYR_GENERIC=1: always the generic pyramid kernel (A/B, parity cross-check)
+    int pyr_generic = 0;   // TW_PYR_GENERIC=1: always the generic pyramid kernel, 2: tw_pyr_level_lds for every level (A/B)
     int blur_variant = 4;  // 4: tw_blur_solve4 (default); 8: tw_blur_solve8 (packed f32) — TW_BLUR_VARIANT
     std::string err;
     // device workspace, shared by all batches (execution is ordered on one stream)
@@ -433,6 +434,7 @@ tw_status get_plan(tw_engine* e, int w0, int h0, Plan** out)
         L.mode = t.mode;
         L.xmax = t.xmax;
         if (L.ksize == 3) memcpy(L.h_kern, kern.data(), sizeof(L.h_kern));
+        L.h_taps = kern;
         L.nrows_max = pyr_nrows_max(t, L.h, h0, L.ksize / 2);
         const size_t lds = (size_t)(PYR_MAXK + (size_t)L.nrows_max * (t.mode == 0 ? PYR_TW : 2 * PYR_TW)) * 4;
         if (lds > 160 * 1024) {
@@ -452,7 +454,7 @@ tw_status get_plan(tw_engine* e, int w0, int h0, Plan** out)
                 span = std::max(span, ((Xlast + r - xlo_a) / 4 + 1) * 4);
             }
             const size_t lds2 = lds + (size_t)L.nrows_max * span;
-            L.pitch_b = (lds2 <= 64 * 1024 && L.ksize <= 63) ? span : 0;
+            L.pitch_b = (lds2 + (size_t)L.nrows_max * 8 + 64 <= 64 * 1024 && L.ksize <= 63) ? span : 0;
         }
 
         tw_status s;
@@ -642,7 +644,19 @@ void launch_pyr(tw_engine* e, hipStream_t st, const Plan* pl, int k, const uint8
         else hipLaunchKernelGGL(tw_pyr_k3<2>, dim3((L.w + 255) / 256, (L.h + 3) / 4, nimg), dim3(256), 0, st, b);
         return;
     }
-    if (L.pitch_b > 0 && !e->pyr_generic) {
+    if (L.pitch_b > 0 && L.mode != 0 && L.ksize >= 7 && e->pyr_generic == 0) {
+        // coarse levels: shared-window row filter (tw_pyr_taps)
+        PyrTapsArgs b;
+        b.p = a;
+        b.pd = (L.pitch_b / 4 + 1) | 1;
+        b.aligned4 = (stride % 4 == 0) ? e->img_aligned4 : 0;
+        memset(b.kext, 0, sizeof(b.kext));
+        memcpy(b.kext + 1, L.h_taps.data(), sizeof(float) * L.ksize);
+        const size_t lds3 = ((size_t)L.nrows_max * (2 * PYR_TW) + (size_t)L.nrows_max * b.pd + 4) * 4;
+        hipLaunchKernelGGL(tw_pyr_taps, grid, dim3(256), lds3, st, b);
+        return;
+    }
+    if (L.pitch_b > 0 && e->pyr_generic != 1) {
         PyrLdsArgs b;
         b.p = a;
         b.pitch_b = L.pitch_b;

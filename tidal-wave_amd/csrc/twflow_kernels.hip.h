@@ -364,6 +364,161 @@ __global__ __launch_bounds__(256) void tw_pyr_level_lds(PyrLdsArgs aa)
 }
 
 // -----------------------------------------------------------------------------------------------------
+// tw_pyr_taps : K1 for the coarse levels (resizing modes, 7 <= ksize <= 63), where the row filter dominates.
+//   Same tile, tables, float operations and order as tw_pyr_level_lds; what changes is how the taps are fed:
+//   * staging: one wave per source row, one dword per lane through a buffer load (no divide, no 64-bit
+//     address math), four rows in flight;
+//   * row filter: one thread produces BOTH source columns X and X+1 an output pixel samples; their tap
+//     windows overlap in all but one byte, so the bytes are read once, as aligned LDS dwords realigned with
+//     v_alignbyte and unpacked with v_cvt_f32_ubyteN;
+//   * coefficients come from the kernel arguments (scalar loads).  kext = [0, k0 .. k(ksize-1), 0 ...]:
+//     window byte j feeds column X with kext[j+1] and column X+1 with kext[j]; the zero entries make the
+//     padded taps add +0 to a non-negative sum, which leaves it unchanged.
+// -----------------------------------------------------------------------------------------------------
+constexpr int PYR_KEXT = 72;
+struct PyrTapsArgs {
+    PyrArgs p;
+    int pd;  // dwords per staged row (odd: the two rows a wave filters start on different banks)
+    int aligned4;
+    float kext[PYR_KEXT];
+};
+
+__global__ __launch_bounds__(256) void tw_pyr_taps(PyrTapsArgs aa)
+{
+    const PyrArgs& a = aa.p;
+    extern __shared__ __attribute__((aligned(16))) float pyr_sm3[];
+    constexpr int P = 2 * PYR_TW;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int x0 = blockIdx.x * PYR_TW, y0 = blockIdx.y * PYR_TH;
+    const uint8_t* __restrict__ src = a.srcs[blockIdx.z];
+    float* __restrict__ dst = a.dst + blockIdx.z * a.dst_zs;
+    const int ksize = a.ksize, r = ksize >> 1;
+    const int yA = y0, yB = min(y0 + PYR_TH - 1, a.h - 1);
+    const int ylo = clampi(a.yofs[yA], 0, a.h0 - 1) - r;
+    const int yhi = clampi(a.yofs[yB] + 1, 0, a.h0 - 1) + r;
+    const int nrows = yhi - ylo + 1;
+    float* rowbuf = pyr_sm3;                                             // [nrows_max][P]
+    unsigned* tile = (unsigned*)(rowbuf + (size_t)a.nrows_max * P);      // [nrows_max][pd] (+ 4 dwords slack)
+    const int xl = min(x0, a.w - 1), xr = min(x0 + PYR_TW - 1, a.w - 1);
+    const int Xfirst = a.xofs[xl], Xlast = a.xofs[xr] + 1;
+    const int xlo_a = (Xfirst - r) & ~3;
+    const int ndw = (Xlast + r - xlo_a) / 4 + 1;
+    const int pd = aa.pd;
+
+    // ---- stage the u8 region ----
+    {
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(src);
+        const int stride = (int)a.stride;
+        for (int dw = lane; dw < ndw; dw += 64) {
+            const int c0 = xlo_a + 4 * dw;
+            const bool fast = aa.aligned4 && c0 >= 0 && c0 + 3 < a.w0;
+            int cc[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) cc[u] = reflect101(c0 + u, a.w0);
+            for (int rb = wv; rb < nrows; rb += 16) {
+                unsigned v[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int rr = rb + 4 * u;
+                    const int Y = reflect101(ylo + min(rr, nrows - 1), a.h0);
+                    const unsigned ro = (unsigned)(Y * stride);
+                    if (fast) {
+                        v[u] = __builtin_amdgcn_raw_buffer_load_b32(rs, (unsigned)c0 + ro, 0, 0);
+                    } else {
+                        const uint8_t* __restrict__ S = src + ro;
+                        v[u] = (unsigned)S[cc[0]] | ((unsigned)S[cc[1]] << 8) | ((unsigned)S[cc[2]] << 16) |
+                               ((unsigned)S[cc[3]] << 24);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int rr = rb + 4 * u;
+                    if (rr < nrows) tile[rr * pd + dw] = v[u];
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- row filter: columns X and X+1 of one output pixel per thread ----
+    {
+        const int q = tid & 31;
+        const int oxp = min(x0 + q, a.w - 1);
+        const int o = a.xofs[oxp] - r - xlo_a;  // first window byte, >= 0
+        const int sh = o & 3;
+        const int ngroups = (ksize + 4) >> 2;   // window = ksize + 1 bytes
+        for (int rr = tid >> 5; rr < nrows; rr += 8) {
+            const unsigned* D = tile + rr * pd + (o >> 2);
+            unsigned lo = D[0];
+            float sA = 0.f, sB = 0.f;
+            for (int g = 0; g < ngroups; g++) {
+                const unsigned hi = D[g + 1];
+                const unsigned wd = __builtin_amdgcn_alignbyte(hi, lo, sh);
+                lo = hi;
+                const float t0 = (float)(wd & 0xffu), t1 = (float)((wd >> 8) & 0xffu);
+                const float t2 = (float)((wd >> 16) & 0xffu), t3 = (float)(wd >> 24);
+                const float* kk = aa.kext + 4 * g;
+                sA += kk[1] * t0;
+                sB += kk[0] * t0;
+                sA += kk[2] * t1;
+                sB += kk[1] * t1;
+                sA += kk[3] * t2;
+                sB += kk[2] * t2;
+                sA += kk[4] * t3;
+                sB += kk[3] * t3;
+            }
+            f32x2 o2;
+            o2.x = sA;
+            o2.y = sB;
+            *(f32x2*)(rowbuf + rr * P + 2 * q) = o2;
+        }
+    }
+    __syncthreads();
+
+    // ---- column filter at the sampled rows + resize combine (as tw_pyr_level) ----
+    const int tx = tid & (PYR_TW - 1), ty = tid / PYR_TW;
+    const int ox = x0 + tx, oy = y0 + ty;
+    if (ox >= a.w || oy >= a.h) return;
+    const int sy = a.yofs[oy];
+    const int s0 = clampi(sy, 0, a.h0 - 1) - ylo, s1 = clampi(sy + 1, 0, a.h0 - 1) - ylo;
+    const float* kc = aa.kext + 1 + r;
+    // both columns of a sample row at once (one 8-byte LDS read per tap row)
+    auto colf2 = [&](int srow) -> f32x2 {
+        const float* R = rowbuf + srow * P + 2 * tx;
+        const f32x2 c = *(const f32x2*)R;
+        float sa = kc[0] * c.x, sb = kc[0] * c.y;
+        for (int j = 1; j <= r; j++) {
+            const f32x2 up = *(const f32x2*)(R + j * P), dn = *(const f32x2*)(R - j * P);
+            sa += kc[j] * (up.x + dn.x);
+            sb += kc[j] * (up.y + dn.y);
+        }
+        f32x2 o2;
+        o2.x = sa;
+        o2.y = sb;
+        return o2;
+    };
+    const f32x2 c0 = colf2(s0), c1 = colf2(s1);
+    float out;
+    if (a.mode == 2) {
+        float sum = 0.f;
+        sum += c0.x + c0.y + c1.x + c1.y;
+        out = sum * 0.25f;
+    } else {
+        float t0, t1;
+        if (ox < a.xmax) {
+            const float a0 = a.alpha[2 * ox], a1 = a.alpha[2 * ox + 1];
+            t0 = c0.x * a0 + c0.y * a1;
+            t1 = c1.x * a0 + c1.y * a1;
+        } else {
+            t0 = c0.x * 1.f;
+            t1 = c1.x * 1.f;
+        }
+        out = t0 * a.beta[2 * oy] + t1 * a.beta[2 * oy + 1];
+    }
+    dst[(long long)oy * a.ld + ox] = out;
+}
+
+// -----------------------------------------------------------------------------------------------------
 // tw_pyr_k3<MODE> : register-only fast path of K1 for 3-tap smoothing (the two finest levels of a
 //   pyr_scale = 0.5 pyramid: MODE 0 = level 0, same size; MODE 2 = level 1, exact 2x2 area-fast resize).
 //   A thread reads whole dwords of the u8 rows (coalesced), converts with v_cvt_f32_ubyteN and produces
