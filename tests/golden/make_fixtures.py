@@ -112,18 +112,13 @@ def main():
         write_pgm(os.path.join(OUT, f"{rev}_{sc}_{stem}.pgm"), g)
         print(rev, sc, name, g.shape)
 
-    # directory tree for the node-level test (tidal-wave_amd/host/test_reference.js): the PNG fixtures verbatim
-    # (data files of the reference's test-suite) and the JPEG fixtures as their gray decode (.pgm), because the
-    # host layer has no JPEG decoder yet
+    # directory tree for the node-level test (tidal-wave_amd/host/test_reference.js): the PNG and JPEG fixtures
+    # verbatim (data files of the reference's test-suite); the host layer decodes both
     import shutil
     for rev, sc, name in IMAGES:
         d = os.path.join(OUT, "tree", rev, sc)
         os.makedirs(d, exist_ok=True)
-        stem = os.path.splitext(name)[0]
-        if name.endswith(".png"):
-            shutil.copyfile(os.path.join(REF, rev, sc, name), os.path.join(d, name))
-        else:
-            shutil.copyfile(os.path.join(OUT, f"{rev}_{sc}_{stem}.pgm"), os.path.join(d, stem + ".pgm"))
+        shutil.copyfile(os.path.join(REF, rev, sc, name), os.path.join(d, name))
 
     def resp(status, h, w, vec, expect, target):
         return {

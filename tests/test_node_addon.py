@@ -16,6 +16,12 @@ needs_node = pytest.mark.skipif(shutil.which("node") is None or not os.path.exis
                                 reason="node or the built addon is not available")
 
 
+def sys_path_oracle():
+    import sys
+    if os.path.join(ROOT, "oracle") not in sys.path:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+
 def node(script, *args, timeout=120):
     return subprocess.run(["node", "-e", script, *args], cwd=HOST, capture_output=True, text=True, timeout=timeout)
 
@@ -63,6 +69,89 @@ def test_png_decode_matches_golden_gray(tmp_path):
         got = np.fromfile(out, np.uint8).reshape(h, w)
         want = O.read_pgm(os.path.join(ROOT, "tests", "golden", "%s_scenario2_capture2.pgm" % rev))
         assert np.array_equal(got, want)
+
+
+DECODE_JS = ("var a=require('./build/Release/tidalwave'); var d=a.decodeGray(process.argv[1]);"
+             "require('fs').writeFileSync(process.argv[2], d.data); console.log(d.width+' '+d.height)")
+
+
+def decode_gray(path, out):
+    r = node(DECODE_JS, str(path), str(out))
+    if r.returncode != 0:
+        return None
+    w, h = map(int, r.stdout.split())
+    return np.fromfile(out, np.uint8).reshape(h, w)
+
+
+@needs_node
+def test_jpeg_fixture_decode_matches_golden_gray(tmp_path):
+    """Host JPEG decode (progressive Huffman, integer IDCT, luma only) of the reference's capture1.jpg == the
+    committed gray decode (tests/golden/*_scenario1_capture1.pgm, written by make_fixtures.py with libjpeg)."""
+    sys_path_oracle()
+    import oracle as O
+    for rev in ("expected", "revision1", "revision2"):
+        jpg = os.path.join(ROOT, "tests", "golden", "tree", rev, "scenario1", "capture1.jpg")
+        got = decode_gray(jpg, tmp_path / (rev + ".bin"))
+        want = O.read_pgm(os.path.join(ROOT, "tests", "golden", "%s_scenario1_capture1.pgm" % rev))
+        assert got is not None and np.array_equal(got, want)
+
+
+@needs_node
+def test_jpeg_decode_matches_libjpeg_on_written_files(tmp_path):
+    """Baseline / progressive, 4:4:4 / 4:2:2 / 4:2:0 / gray, restart markers, optimised tables: JPEGs written
+    here by PIL (libjpeg-turbo) decode to the same luma bytes as libjpeg's own gray decode."""
+    Image = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(5)
+    noise = rng.integers(0, 256, (157, 211, 3)).astype(np.uint8)
+    yy, xx = np.mgrid[0:157, 0:211]
+    smooth = np.stack([(xx * 1.2 + yy * 0.3) % 256, np.sin(xx / 9.) * 100 + 128, (yy * 1.5) % 256], -1).astype(np.uint8)
+    smooth[40:80, 50:120] = noise[40:80, 50:120]
+    cases = []
+    for name, img in (("noise", noise), ("smooth", smooth)):
+        for prog in (False, True):
+            for ss in (0, 1, 2):
+                for q, rst in ((35, 0), (90, 3)):
+                    kw = dict(quality=q, progressive=prog, subsampling=ss)
+                    if rst:
+                        kw["restart_marker_blocks"] = rst
+                    p = tmp_path / ("%s_p%d_s%d_q%d_r%d.jpg" % (name, prog, ss, q, rst))
+                    Image.fromarray(img).save(p, **kw)
+                    cases.append(p)
+    for prog in (False, True):
+        p = tmp_path / ("gray%d.jpg" % prog)
+        Image.fromarray(smooth[..., 0]).save(p, quality=80, progressive=prog, optimize=True)
+        cases.append(p)
+    for p in cases:
+        im = Image.open(p)
+        im.draft("L", im.size)
+        want = np.asarray(im.convert("L"), dtype=np.uint8)
+        got = decode_gray(p, str(p) + ".bin")
+        assert got is not None and got.shape == want.shape and np.array_equal(got, want), p.name
+
+
+@needs_node
+def test_jpeg_decode_survives_damaged_files(tmp_path):
+    """Truncated and bit-flipped JPEGs either decode to something or fail cleanly (an imread failure is
+    "Can't open <path>", src/opticalflow.cpp:40) — never a crash of the host process."""
+    src = open(os.path.join(ROOT, "tests", "golden", "tree", "expected", "scenario1", "capture1.jpg"), "rb").read()
+    rng = np.random.default_rng(11)
+    files = []
+    for i, cut in enumerate((3, 20, 200, len(src) // 3, len(src) // 2, len(src) - 2)):
+        p = tmp_path / ("cut%d.jpg" % i)
+        p.write_bytes(src[:cut])
+        files.append(p)
+    for i in range(12):
+        b = bytearray(src)
+        for pos in rng.integers(2, len(b), 8):
+            b[int(pos)] = int(rng.integers(0, 256))
+        p = tmp_path / ("flip%d.jpg" % i)
+        p.write_bytes(bytes(b))
+        files.append(p)
+    script = ("var a=require('./build/Release/tidalwave'); var n=0;"
+              "process.argv.slice(1).forEach(function(f){ try { a.decodeGray(f); n++; } catch(e) {} });"
+              "console.log('done '+n)")
+    r = node(script, *[str(f) for f in files])
+    assert r.returncode == 0 and r.stdout.startswith("done"), r.stderr[-400:]
 
 
 @needs_node

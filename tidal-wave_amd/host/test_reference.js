@@ -1,6 +1,6 @@
 // test_reference.js — plain-node restatement of the reference's mocha suite (/root/reference/test/index.coffee:
 // 4 cases) against this addon.  Needs a HIP device (the engine has no CPU path).  Fixture tree:
-// tests/golden/tree (PNG fixtures verbatim; the JPEG fixtures as .pgm gray decodes).
+// tests/golden/tree (the reference's PNG and JPEG fixture files, verbatim).
 'use strict';
 var TidalWave = require('./index');
 var assert = require('assert');
@@ -22,7 +22,7 @@ var tests = [
   ['should report nothing on "revision1"', function(done) {
     var t = createWithExpectDir('revision1');
     t.on('data', function(data) {
-      if (~data.target_image.indexOf('capture1')) expectOK(data, 'revision1', 'scenario1', 'capture1.pgm', 279, 280);
+      if (~data.target_image.indexOf('capture1')) expectOK(data, 'revision1', 'scenario1', 'capture1.jpg', 279, 280);
       else if (~data.target_image.indexOf('capture2')) expectOK(data, 'revision1', 'scenario2', 'capture2.png', 117, 180);
       else assert.fail('Cannot be here.');
     });
@@ -32,7 +32,7 @@ var tests = [
   ['should report something on "revision2"', function(done) {
     var t = createWithExpectDir('revision2');
     t.on('data', function(data) {
-      if (~data.target_image.indexOf('capture1')) expectOK(data, 'revision2', 'scenario1', 'capture1.pgm', 279, 280);
+      if (~data.target_image.indexOf('capture1')) expectOK(data, 'revision2', 'scenario1', 'capture1.jpg', 279, 280);
       else if (~data.target_image.indexOf('capture2')) {
         delete data.time;
         assert.deepStrictEqual(Object.keys(data), ['status', 'span', 'threshold', 'expect_image', 'target_image', 'height', 'width', 'vector']);

@@ -170,7 +170,8 @@ bool load_gray(const std::string& path, std::vector<uint8_t>& img, int& w, int& 
     if (!read_file(path, d) || d.size() < 8) return false;
     if (d[0] == 'P' && d[1] == '5') return decode_pgm(d, img, w, h);
     if (d[0] == 0x89 && d[1] == 'P') return decode_png(d, img, w, h);
-    return false;  // JPEG and the other cv::imread formats are not decoded yet
+    if (d[0] == 0xFF && d[1] == 0xD8) return decode_jpeg_gray(d.data(), d.size(), img, w, h);
+    return false;  // the other cv::imread formats (BMP, TIFF, JPEG-2000, ...) are not decoded
 }
 
 // cv::resize on CV_8UC1, INTER_LINEAR, 11-bit fixed point (imgproc/imgwarp.cpp: HResizeLinear<uchar,int,short>,

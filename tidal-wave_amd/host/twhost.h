@@ -94,7 +94,9 @@ private:
     bool running_ = true;
 };
 
-// 8-bit gray decode of a file: PGM (P5) and PNG (zlib inflate + unfilter, libpng-1.5 gray conversion).
+// JPEG (baseline / progressive Huffman, 8-bit) -> luma plane, libjpeg's integer IDCT (jpeg_gray.cpp)
+bool decode_jpeg_gray(const uint8_t* data, size_t n, std::vector<uint8_t>& img, int& w, int& h);
+// 8-bit gray decode of a file: PGM (P5), PNG (zlib inflate + unfilter, libpng-1.5 gray conversion) and JPEG.
 // Returns false if the file cannot be opened / decoded ("Can't open <path>", src/opticalflow.cpp:40,47).
 bool load_gray(const std::string& path, std::vector<uint8_t>& img, int& w, int& h);
 // cv::resize(8-bit, INTER_LINEAR) — the "<= 5 px" reconcile of src/opticalflow.cpp:64-68.
