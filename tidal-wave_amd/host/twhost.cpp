@@ -225,8 +225,9 @@ void resize_u8_linear(const std::vector<uint8_t>& src, int sw, int sh, std::vect
 // ---------------------------------------------------------------------------------------------------
 // Consumer
 // ---------------------------------------------------------------------------------------------------
-Consumer::Consumer(int id, MessageQueue<Request>& req, MessageQueue<Response>& res, const tw_params& p, int batch)
-    : id_(id), req_(req), res_(res), params_(p), batch_(std::max(1, batch))
+Consumer::Consumer(int id, MessageQueue<Request>& req, MessageQueue<Response>& res, const tw_params& p, int batch,
+                   int decode_threads)
+    : id_(id), req_(req), res_(res), params_(p), batch_(std::max(1, batch)), decode_threads_(std::max(1, decode_threads))
 {
 }
 Consumer::~Consumer() { join(); }
@@ -285,8 +286,20 @@ void Consumer::run()
             jobs.emplace_back();
             jobs.back().req = std::move(more);
         }
+        // decode pool: once the flow runs on the GPU the two imreads of a pair are > 99 % of the wall time
+        // (SURVEY §8 f1), so the pairs of a batch are decoded side by side
+        {
+            const size_t nt = std::min(jobs.size(), (size_t)decode_threads_);
+            std::atomic<size_t> next{0};
+            auto worker = [&] {
+                for (size_t i = next++; i < jobs.size(); i = next++) prepare(jobs[i]);
+            };
+            std::vector<std::thread> pool;
+            for (size_t t = 1; t < nt; t++) pool.emplace_back(worker);
+            worker();
+            for (std::thread& t : pool) t.join();
+        }
         for (Staged& s : jobs) {
-            prepare(s);
             if (s.err.empty() && !eng) s.err = eng_err;
             if (s.err.empty()) {
                 tw_status r = tw_submit_u8(eng, s.a.data(), s.b.data(), s.w, s.h, s.w, s.req.span, s.req.threshold, &s.ticket);
@@ -347,8 +360,12 @@ void Manager::start(const Parameter& p)
     // device, so the surplus is folded into the per-consumer batch instead
     const int n = std::max(1, ndev > 0 ? std::min(p.numThreads, ndev) : 1);
     const int batch = std::max(1, std::min(32, p.numThreads * 2));
+    // decode threads per consumer: TW_DECODE_THREADS, else the host cores shared between the consumers
+    int dec = 0;
+    if (const char* ev = getenv("TW_DECODE_THREADS")) dec = atoi(ev);
+    if (dec <= 0) dec = std::max(1, std::min(16, (int)std::thread::hardware_concurrency() / n));
     for (int i = 0; i < n; i++) {
-        consumers_.push_back(new Consumer(i, requestQueue_, responseQueue_, p.optParam, batch));
+        consumers_.push_back(new Consumer(i, requestQueue_, responseQueue_, p.optParam, batch, dec));
         consumers_.back()->start();
     }
     pump_ = std::thread([this] { work(); });

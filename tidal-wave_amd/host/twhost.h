@@ -114,7 +114,8 @@ struct Observer {
 // has no CPU path).
 class Consumer {
 public:
-    Consumer(int id, MessageQueue<Request>& req, MessageQueue<Response>& res, const tw_params& p, int batch);
+    Consumer(int id, MessageQueue<Request>& req, MessageQueue<Response>& res, const tw_params& p, int batch,
+             int decode_threads);
     ~Consumer();
     void start();
     void join();
@@ -126,6 +127,7 @@ private:
     MessageQueue<Response>& res_;
     tw_params params_;
     int batch_;
+    int decode_threads_;  // images of a batch are decoded by this many threads
     std::thread th_;
 };
 
