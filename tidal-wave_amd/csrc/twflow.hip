@@ -288,6 +288,7 @@ struct tw_engine {
                            // include the co-running kernel
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int upd_ny = 2;        // TW_UPD_NY: pixels per lane of tw_update_matrices (1 or 2)
     int pyr_generic = 0;   // TW_PYR_GENERIC=1: always the generic pyramid kernel, 2: tw_pyr_level_lds for every level (A/B)
     int blur_variant = 4;  // 4: tw_blur_solve4 (default); 8: tw_blur_solve8 (packed f32) — TW_BLUR_VARIANT
     std::string err;
@@ -597,6 +598,17 @@ struct ProfScope {
     }
 };
 
+// tw_update_matrices<UPSAMPLE, NY>: NY pixels of a column per lane (TW_UPD_NY, default 2)
+template <bool UP>
+void launch_upd_kernel(tw_engine* e, hipStream_t st, int w, int h, int npairs, const UpdArgs& a)
+{
+    if (e->upd_ny == 1) {
+        hipLaunchKernelGGL((tw_update_matrices<UP, 1>), dim3((w + 63) / 64, (h + 3) / 4, npairs), dim3(256), 0, st, a);
+    } else {
+        hipLaunchKernelGGL((tw_update_matrices<UP, 2>), dim3((w + 63) / 64, (h + 7) / 8, npairs), dim3(256), 0, st, a);
+    }
+}
+
 // ---- kernel launch helpers (nz = images or pairs in this launch) -------------------------------------
 void launch_pyr(tw_engine* e, hipStream_t st, const Plan* pl, int k, const uint8_t* const* d_srcs, long long stride,
                 float* I, int nimg)
@@ -747,7 +759,7 @@ void launch_blur(tw_engine* e, hipStream_t st, int w, int h, int ld, long long p
             u.ps = ps;
             u.fps = ps;
             ProfScope pscope(e, st, TW_K_UPDATE_MATRICES, level);
-            hipLaunchKernelGGL(tw_update_matrices<false>, dim3((w + 63) / 64, (h + 3) / 4, npairs), dim3(256), 0, st, u);
+            launch_upd_kernel<false>(e, st, w, h, npairs, u);
         }
         if (level < 0) (void)hipStreamSynchronize(st);  // tmp is freed on return
         return;
@@ -785,7 +797,6 @@ void launch_update(tw_engine* e, hipStream_t st, const Plan* pl, int k, const fl
     a.ld = L.ld;
     a.ps = L.ps;
     a.fps = L.ps;
-    dim3 grid((L.w + 63) / 64, (L.h + 3) / 4, npairs);
     ProfScope pscope(e, st, TW_K_UPDATE_MATRICES, k);
     if (k < pl->levels) {
         const LevelPlan& P = pl->lv[k + 1];
@@ -800,10 +811,10 @@ void launch_update(tw_engine* e, hipStream_t st, const Plan* pl, int k, const fl
         a.beta = L.d_ubeta;
         a.xmax = L.uxmax;
         a.scale = (float)(1. / e->p.pyrScale);
-        hipLaunchKernelGGL(tw_update_matrices<true>, grid, dim3(256), 0, st, a);
+        launch_upd_kernel<true>(e, st, L.w, L.h, npairs, a);
     } else {
         a.zero_flow = 1;
-        hipLaunchKernelGGL(tw_update_matrices<false>, grid, dim3(256), 0, st, a);
+        launch_upd_kernel<false>(e, st, L.w, L.h, npairs, a);
     }
 }
 
@@ -1087,6 +1098,7 @@ tw_status tw_engine_create(int device, const tw_params* params, int slots, tw_en
     e->box = (p.flags & 256) ? 0 : 1;
     if (const char* ev = getenv("TW_BLUR_VARIANT")) e->blur_variant = atoi(ev);
     if (const char* ev = getenv("TW_PYR_GENERIC")) e->pyr_generic = atoi(ev);
+    if (const char* ev = getenv("TW_UPD_NY")) e->upd_ny = atoi(ev) == 1 ? 1 : 2;
     if (const char* ev = getenv("TW_LANES")) e->lanes = std::min(2, std::max(1, atoi(ev)));
     bool ok = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) == hipSuccess &&
               hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking) == hipSuccess &&
@@ -1416,7 +1428,7 @@ extern "C" int tw_debug_occupancy(char* buf, int cap)
     add("tw_blur_solve8<15,256>", (const void*)tw_blur_solve8<15, 256, 16, 8, true, true>, 256, 0);
     add("tw_blur_solve8<15,128>", (const void*)tw_blur_solve8<15, 128, 16, 8, true, true>, 128, 0);
     add("tw_polyexp<7>", (const void*)tw_polyexp<7>, 256, 0);
-    add("tw_update_matrices<true>", (const void*)tw_update_matrices<true>, 256, 0);
+    add("tw_update_matrices<true,2>", (const void*)tw_update_matrices<true, 2>, 256, 0);
     add("tw_pyr_k3<0>", (const void*)tw_pyr_k3<0>, 256, 0);
     return n;
 }
@@ -1608,7 +1620,7 @@ tw_status tw_stage_update_matrices(tw_engine* e, const float* R0_5, const float*
     a.ps = ps;
     a.fps = ps;
     hipStream_t st = e->stream;
-    hipLaunchKernelGGL(tw_update_matrices<false>, dim3((w + 63) / 64, (h + 3) / 4, 1), dim3(256), 0, st, a);
+    launch_upd_kernel<false>(e, st, w, h, 1, a);
     TW_HIP(e, hipGetLastError());
     TW_HIP(e, hipStreamSynchronize(st));
     return down_planes(e, M5, d_M, ld, ps, w, h, 5);
@@ -1661,7 +1673,7 @@ tw_status tw_stage_flow_upsample_update(tw_engine* e, const float* R0_5, const f
     a.xmax = u.xmax;
     a.scale = (float)(1. / e->p.pyrScale);
     hipStream_t st = e->stream;
-    hipLaunchKernelGGL(tw_update_matrices<true>, dim3((w + 63) / 64, (h + 3) / 4, 1), dim3(256), 0, st, a);
+    launch_upd_kernel<true>(e, st, w, h, 1, a);
     TW_HIP(e, hipGetLastError());
     TW_HIP(e, hipStreamSynchronize(st));
     if ((r = down_planes(e, flow2, d_f, ld, ps, w, h, 2))) return r;

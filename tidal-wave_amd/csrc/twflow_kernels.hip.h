@@ -755,33 +755,45 @@ __global__ __launch_bounds__(256) void tw_polyexp(PolyArgs a)
 // FarnebackUpdateMatrices for one pixel (optflowgf.cpp): warp R1 by the flow (bilinear gather of 5
 // coefficients), combine with R0, border attenuation, form G11,G12,G22,h1,h2.  All float.
 // =====================================================================================================
-__device__ __forceinline__ void update_matrices_px(const float* __restrict__ R0, const float* __restrict__ R1,
-                                                   long long ps, int ld, int w, int h, int x, int y, float dx,
-                                                   float dy, float M[5])
+struct UpdTaps {
+    float t[5][4];  // the 2x2 neighbourhood of R1 at (x + dx, y + dy), 5 coefficients
+    float fx, fy;   // fractional position
+    bool inb;
+};
+// the flow-dependent gather of FarnebackUpdateMatrices (loads only)
+__device__ __forceinline__ void update_matrices_gather(const float* __restrict__ R1, long long ps, int ld, int w, int h,
+                                                       int x, int y, float dx, float dy, UpdTaps& T)
 {
-    const long long o = (long long)y * ld + x;
     float fx = (float)x + dx, fy = (float)y + dy;
     const float flx = floorf(fx), fly = floorf(fy);
-    float r2, r3, r4, r5, r6;
     // (unsigned)x1 < (unsigned)(w-1) && (unsigned)y1 < (unsigned)(h-1), with cvFloor's INT_MIN for
     // out-of-range / NaN inputs: evaluated on the floats (exact: |.| < 2^24 inside the branch)
     const bool inb = flx >= 0.f && flx < (float)(w - 1) && fly >= 0.f && fly < (float)(h - 1);
     // Branch-free: the 4x5 taps are always gathered (from a clamped, valid position) and discarded when the
     // sample falls outside, so that the loads of several pixels can be in flight together.
     const int x1 = inb ? (int)flx : 0, y1 = inb ? (int)fly : 0;
-    fx -= (float)x1;
-    fy -= (float)y1;
-    const float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
+    T.fx = fx - (float)x1;
+    T.fy = fy - (float)y1;
+    T.inb = inb;
     const float* p = R1 + (long long)y1 * ld + x1;
-    float t[5][4];
 #pragma unroll
     for (int c = 0; c < 5; c++) {
-        t[c][0] = p[c * ps];
-        t[c][1] = p[c * ps + 1];
-        t[c][2] = p[c * ps + ld];
-        t[c][3] = p[c * ps + ld + 1];
+        T.t[c][0] = p[c * ps];
+        T.t[c][1] = p[c * ps + 1];
+        T.t[c][2] = p[c * ps + ld];
+        T.t[c][3] = p[c * ps + ld + 1];
     }
-    const float q0 = R0[o], q1 = R0[o + ps], q2 = R0[o + 2 * ps], q3 = R0[o + 3 * ps], q4 = R0[o + 4 * ps];
+}
+// ... and its arithmetic
+__device__ __forceinline__ void update_matrices_combine(const float q[5], const UpdTaps& T, int w, int h, int x, int y,
+                                                        float dx, float dy, float M[5])
+{
+    const float fx = T.fx, fy = T.fy;
+    const bool inb = T.inb;
+    const float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
+    const float(&t)[5][4] = T.t;
+    float r2, r3, r4, r5, r6;
+    const float q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4];
     if (inb) {
         r2 = a00 * t[0][0] + a01 * t[0][1] + a10 * t[0][2] + a11 * t[0][3];
         r3 = a00 * t[1][0] + a01 * t[1][1] + a10 * t[1][2] + a11 * t[1][3];
@@ -825,9 +837,25 @@ __device__ __forceinline__ void update_matrices_px(const float* __restrict__ R0,
     M[3] = r4 * r2 + r6 * r3;
     M[4] = r6 * r2 + r5 * r3;
 }
+__device__ __forceinline__ void update_matrices_core(const float q[5], const float* __restrict__ R1,
+                                                     long long ps, int ld, int w, int h, int x, int y, float dx,
+                                                     float dy, float M[5])
+{
+    UpdTaps T;
+    update_matrices_gather(R1, ps, ld, w, h, x, y, dx, dy, T);
+    update_matrices_combine(q, T, w, h, x, y, dx, dy, M);
+}
+__device__ __forceinline__ void update_matrices_px(const float* __restrict__ R0, const float* __restrict__ R1,
+                                                   long long ps, int ld, int w, int h, int x, int y, float dx,
+                                                   float dy, float M[5])
+{
+    const long long o = (long long)y * ld + x;
+    const float q[5] = {R0[o], R0[o + ps], R0[o + 2 * ps], R0[o + 3 * ps], R0[o + 4 * ps]};
+    update_matrices_core(q, R1, ps, ld, w, h, x, y, dx, dy, M);
+}
 
 // =====================================================================================================
-// K6  tw_update_matrices<UPSAMPLE> : first FarnebackUpdateMatrices of a level.  UPSAMPLE fuses
+// K6  tw_update_matrices<UPSAMPLE, NY> : first FarnebackUpdateMatrices of a level.  UPSAMPLE fuses
 //   resize(prevFlow, INTER_LINEAR) + flow *= 1/pyr_scale (and writes the level's initial flow);
 //   otherwise the flow planes are read (zero-initialised at the coarsest level).
 // =====================================================================================================
@@ -850,57 +878,92 @@ struct UpdArgs {
     int zero_flow;  // coarsest level: flow = 0 (written)
 };
 
-template <bool UPSAMPLE>
+template <bool UPSAMPLE, int NY>
 __global__ __launch_bounds__(256) void tw_update_matrices(UpdArgs a)
 {
+    // One lane = NY pixels of one column (rows 4 apart).  Everything that does not depend on the flow (the R0
+    // coefficients, the coarse flow taps) is loaded first and without branches, so that a wave has two
+    // dependent memory round trips (flow -> gather) instead of three and NY x the loads in flight.
     int bx, by, z;
     xcd_remap(bx, by, z);  // an XCD works on a contiguous band of rows: the R1 rows a tile gathers stay in its L2
     const int x = bx * 64 + (threadIdx.x & 63);
-    const int y = by * 4 + (threadIdx.x >> 6);
-    if (x >= a.w || y >= a.h) return;
-    const long long o = (long long)y * a.ld + x;
+    const int yb = by * (4 * NY) + (threadIdx.x >> 6);
+    if (x >= a.w || yb >= a.h) return;
     const float* __restrict__ R0 = a.R + (long long)(2 * z) * 5 * a.ps;
     const float* __restrict__ R1 = R0 + 5 * a.ps;
     float* __restrict__ flow = a.flow + (long long)z * 2 * a.fps;
     float* __restrict__ Mo = a.M + (long long)z * 5 * a.ps;
-    float dx, dy;
+    int yy[NY];
+    long long o[NY];
+    float q[NY][5], dx[NY], dy[NY];
+#pragma unroll
+    for (int j = 0; j < NY; j++) {
+        yy[j] = min(yb + 4 * j, a.h - 1);  // rows past the bottom repeat the last one (their stores are skipped)
+        o[j] = (long long)yy[j] * a.ld + x;
+#pragma unroll
+        for (int c = 0; c < 5; c++) q[j][c] = R0[o[j] + c * a.ps];
+    }
     if (UPSAMPLE) {
         const int sx = a.xofs[x];
-        const int sy = a.yofs[y];
-        const int r0 = clampi(sy, 0, a.ph - 1), r1 = clampi(sy + 1, 0, a.ph - 1);
-        const float b0 = a.beta[2 * y], b1 = a.beta[2 * y + 1];
+        const int sx1 = min(sx + 1, a.pw - 1);
+        const bool two = x < a.xmax;
+        const float a0 = a.alpha[2 * x], a1 = a.alpha[2 * x + 1];
         const float* __restrict__ prev = a.prev + (long long)z * 2 * a.pfps;
-        const float* P0 = prev + (long long)r0 * a.pld + sx;
-        const float* P1 = prev + (long long)r1 * a.pld + sx;
-        float t0x, t1x, t0y, t1y;
-        if (x < a.xmax) {
-            const float a0 = a.alpha[2 * x], a1 = a.alpha[2 * x + 1];
-            t0x = P0[0] * a0 + P0[1] * a1;
-            t1x = P1[0] * a0 + P1[1] * a1;
-            t0y = P0[a.pfps] * a0 + P0[a.pfps + 1] * a1;
-            t1y = P1[a.pfps] * a0 + P1[a.pfps + 1] * a1;
-        } else {
-            t0x = P0[0] * 1.f;
-            t1x = P1[0] * 1.f;
-            t0y = P0[a.pfps] * 1.f;
-            t1y = P1[a.pfps] * 1.f;
-        }
-        dx = (t0x * b0 + t1x * b1) * a.scale + 0.f;
-        dy = (t0y * b0 + t1y * b1) * a.scale + 0.f;
-        flow[o] = dx;
-        flow[o + a.fps] = dy;
-    } else if (a.zero_flow) {
-        dx = dy = 0.f;
-        flow[o] = 0.f;
-        flow[o + a.fps] = 0.f;
-    } else {
-        dx = flow[o];
-        dy = flow[o + a.fps];
-    }
-    float M[5];
-    update_matrices_px(R0, R1, a.ps, a.ld, a.w, a.h, x, y, dx, dy, M);
+        float p[NY][8], b0[NY], b1[NY];
 #pragma unroll
-    for (int c = 0; c < 5; c++) Mo[o + c * a.ps] = M[c];
+        for (int j = 0; j < NY; j++) {
+            const int sy = a.yofs[yy[j]];
+            const int r0 = clampi(sy, 0, a.ph - 1), r1 = clampi(sy + 1, 0, a.ph - 1);
+            b0[j] = a.beta[2 * yy[j]];
+            b1[j] = a.beta[2 * yy[j] + 1];
+            const float* P0 = prev + (long long)r0 * a.pld;
+            const float* P1 = prev + (long long)r1 * a.pld;
+            p[j][0] = P0[sx];
+            p[j][1] = P0[sx1];
+            p[j][2] = P1[sx];
+            p[j][3] = P1[sx1];
+            p[j][4] = P0[a.pfps + sx];
+            p[j][5] = P0[a.pfps + sx1];
+            p[j][6] = P1[a.pfps + sx];
+            p[j][7] = P1[a.pfps + sx1];
+        }
+#pragma unroll
+        for (int j = 0; j < NY; j++) {
+            // dx >= xmax: HResizeLinear's single-tap tail (S[sx] * 1)
+            const float t0x = two ? p[j][0] * a0 + p[j][1] * a1 : p[j][0] * 1.f;
+            const float t1x = two ? p[j][2] * a0 + p[j][3] * a1 : p[j][2] * 1.f;
+            const float t0y = two ? p[j][4] * a0 + p[j][5] * a1 : p[j][4] * 1.f;
+            const float t1y = two ? p[j][6] * a0 + p[j][7] * a1 : p[j][6] * 1.f;
+            dx[j] = (t0x * b0[j] + t1x * b1[j]) * a.scale + 0.f;
+            dy[j] = (t0y * b0[j] + t1y * b1[j]) * a.scale + 0.f;
+        }
+    } else if (a.zero_flow) {
+#pragma unroll
+        for (int j = 0; j < NY; j++) dx[j] = dy[j] = 0.f;
+    } else {
+#pragma unroll
+        for (int j = 0; j < NY; j++) {
+            dx[j] = flow[o[j]];
+            dy[j] = flow[o[j] + a.fps];
+        }
+    }
+    float M[NY][5];
+    UpdTaps T[NY];
+#pragma unroll
+    for (int j = 0; j < NY; j++) update_matrices_gather(R1, a.ps, a.ld, a.w, a.h, x, yy[j], dx[j], dy[j], T[j]);
+#pragma unroll
+    for (int j = 0; j < NY; j++) update_matrices_combine(q[j], T[j], a.w, a.h, x, yy[j], dx[j], dy[j], M[j]);
+#pragma unroll
+    for (int j = 0; j < NY; j++) {
+        if (yb + 4 * j < a.h) {
+            if (UPSAMPLE || a.zero_flow) {
+                flow[o[j]] = dx[j];
+                flow[o[j] + a.fps] = dy[j];
+            }
+#pragma unroll
+            for (int c = 0; c < 5; c++) Mo[o[j] + c * a.ps] = M[j][c];
+        }
+    }
 }
 
 // =====================================================================================================
