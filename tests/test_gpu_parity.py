@@ -260,6 +260,22 @@ def test_config5_parameters_reduced_size(twflow, oracle):
     assert_same(gy, wy, "config-5 flowy")
 
 
+def test_config5_full_size_4k(twflow, oracle):
+    """BASELINE config 5 at its full size: one 3840x2160 pair, pyrLevels 5, winSize 50, iters 5 (six pyramid
+    levels) — the whole flow field and the scan, bit for bit against the oracle (about 20 s of CPU)."""
+    import synth
+    kw = dict(pyrLevels=5, winSize=50, pyrIterations=5)
+    a, b = synth.make_pair(1, 2160, 3840)
+    with twflow.Engine(0, twflow.default_params(**kw), slots=2) as e:
+        assert e.num_levels(3840, 2160) == 5
+        r = e.wait(e.submit(a, b))
+        gx, gy, _ = e.calculate_internal(a, b)
+    wx, wy = oracle.farneback(a, b, oracle.default_params(**kw))
+    assert_same(gx, wx, "4K config-5 flowx")
+    assert_same(gy, wy, "4K config-5 flowy")
+    assert r["vector"] == oracle.span_scan(wx, wy, 10, 5.0)
+
+
 @pytest.mark.parametrize("kw", [dict(flags=0), dict(flags=0, winSize=13, pyrIterations=2), dict(flags=4), dict(flags=260)])
 def test_box_window_and_flag_bits(twflow, oracle, kw):
     """flags without 256 selects FarnebackUpdateFlow_Blur (box window, double running sums); bit 4
