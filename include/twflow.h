@@ -118,6 +118,15 @@ tw_status tw_dev_alloc(tw_engine* e, size_t bytes, void** dptr);
 tw_status tw_dev_free(tw_engine* e, void* dptr);
 tw_status tw_dev_upload(tw_engine* e, void* dptr, const void* host, size_t bytes);
 
+/* Page-locked host memory.  Images handed to tw_submit_u8 from such memory (or from memory the caller
+ * registered with hipHostRegister) are DMA-ed to the device straight from the caller's buffer on the engine's
+ * copy stream — no staging copy — and must therefore stay unchanged until tw_wait() of the ticket returns.
+ * Ordinary (pageable) memory is staged through the engine's own pinned buffers and may be reused as soon as
+ * tw_submit_u8 returns.  Either way the upload of batch j+1 overlaps the kernels of batch j (BASELINE config 3:
+ * "pinned H2D/D2H overlapped on a side stream"). */
+tw_status tw_host_alloc(tw_engine* e, size_t bytes, void** hptr);
+tw_status tw_host_free(tw_engine* e, void* hptr);
+
 /* ---- instrumentation (bench.py / tests) ---------------------------------------------------------- */
 
 /* Kernel classes, in data-flow order. */

@@ -253,6 +253,11 @@ struct Ctx {
     int w = 0, h = 0, span = 0;
     double threshold = 0;
     bool any_host = false;
+    // device copy of the batch's host images (one region per context: the next batch uploads while this one
+    // computes) and the event that marks its uploads complete on the copy stream
+    uint8_t* d_img = nullptr;
+    size_t d_img_cap = 0;
+    hipEvent_t ev_h2d = nullptr;
     // pinned host memory
     uint8_t* h_img = nullptr;
     size_t h_img_cap = 0;
@@ -297,8 +302,7 @@ struct tw_engine {
     float *I = nullptr, *R = nullptr, *M[2] = {nullptr, nullptr};
     std::vector<float*> flow;            // per level, cap (levels>=1) or chunk0 (level 0) pairs x 2 planes
     std::vector<size_t> flow_cap;
-    uint8_t* d_img = nullptr;
-    size_t d_img_cap = 0;
+    hipStream_t copy_stream = nullptr;  // host -> device image uploads, overlapped with the compute stream
     const uint8_t** d_ptrs = nullptr;  // [2*cap]
     int* d_count = nullptr;            // [cap]
     ScanRec* d_rec = nullptr;          // [cap][G]
@@ -500,9 +504,8 @@ tw_status reserve_workspace(tw_engine* e, const Plan* pl, int span, bool need_im
             const size_t fc = (size_t)pl->lv[k].ps * 2 * (k == 0 ? pl->lv[0].chunk * e->lanes : e->cap);
             if (fc > e->flow_cap[k]) grow = true;
         }
-    const size_t img = staged_image_bytes(pl->w0, pl->h0) * 2 * e->cap;
+    (void)need_img;  // image regions belong to the batch contexts (submit_common)
     const size_t G = span > 0 ? (size_t)tw_grid_capacity(pl->w0, pl->h0, span) : 0;
-    if (need_img && img > e->d_img_cap) grow = true;
     if (G * e->cap > e->d_rec_cap) grow = true;
     if (!grow) return TW_OK;
     TW_HIP(e, hipStreamSynchronize(e->stream));
@@ -540,13 +543,6 @@ tw_status reserve_workspace(tw_engine* e, const Plan* pl, int span, bool need_im
             TW_HIP(e, hipMalloc((void**)&e->flow[k], fc * 4 + 256));
             e->flow_cap[k] = fc;
         }
-    }
-    if (need_img && img > e->d_img_cap) {
-        if (e->d_img) (void)hipFree(e->d_img);
-        e->d_img = nullptr;
-        e->d_img_cap = 0;
-        TW_HIP(e, hipMalloc((void**)&e->d_img, img + 256));
-        e->d_img_cap = img;
     }
     if (G * e->cap > e->d_rec_cap) {
         if (e->d_rec) (void)hipFree(e->d_rec);
@@ -832,15 +828,17 @@ tw_status flush_ctx(tw_engine* e, Ctx& c)
     const size_t npx = staged_image_bytes(c.w, c.h);  // staged images are 256-byte aligned
     long long stride = c.jobs[0].stride;
     if (c.any_host) {
-        TW_HIP(e, hipMemcpyAsync(e->d_img, c.h_img, npx * 2 * n, hipMemcpyHostToDevice, st));
+        // the uploads were queued on the copy stream as the jobs came in (submit_common)
+        TW_HIP(e, hipEventRecord(c.ev_h2d, e->copy_stream));
+        TW_HIP(e, hipStreamWaitEvent(st, c.ev_h2d, 0));
         stride = c.w;
     }
     bool al4 = (stride % 4) == 0;
     for (int j = 0; j < n; j++) {
         const Job& jb = c.jobs[j];
         if (jb.h_a) {
-            c.h_ptrs[2 * j] = e->d_img + npx * (2 * j);
-            c.h_ptrs[2 * j + 1] = e->d_img + npx * (2 * j + 1);
+            c.h_ptrs[2 * j] = c.d_img + npx * (2 * j);
+            c.h_ptrs[2 * j + 1] = c.d_img + npx * (2 * j + 1);
         } else {
             c.h_ptrs[2 * j] = jb.d_a;
             c.h_ptrs[2 * j + 1] = jb.d_b;
@@ -939,6 +937,17 @@ tw_status check_dims(tw_engine* e, int width, int height)
     return TW_OK;
 }
 
+// true for page-locked host memory (hipHostMalloc / hipHostRegister); plain malloc memory makes the query fail
+bool host_pinned(const void* p)
+{
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return at.type == hipMemoryTypeHost;
+}
+
 tw_status submit_common(tw_engine* e, const uint8_t* h_a, const uint8_t* h_b, const void* d_a, const void* d_b,
                         int width, int height, ptrdiff_t stride, int span, double threshold, tw_ticket* ticket)
 {
@@ -981,23 +990,45 @@ tw_status submit_common(tw_engine* e, const uint8_t* h_a, const uint8_t* h_b, co
     if (h_a) {
         const size_t npx = staged_image_bytes(width, height);
         const size_t need = npx * 2 * e->cap;
-        if (need > c->h_img_cap) {
-            // only ever happens on the first job of a batch (all jobs of a batch have one size)
-            if (c->h_img) (void)hipHostFree(c->h_img);
-            c->h_img = nullptr;
-            c->h_img_cap = 0;
-            TW_HIP(e, hipHostMalloc((void**)&c->h_img, need, hipHostMallocDefault));
-            c->h_img_cap = need;
-        }
         const size_t j = c->jobs.size();
-        uint8_t* da = c->h_img + npx * (2 * j);
-        uint8_t* db = c->h_img + npx * (2 * j + 1);
-        for (int y = 0; y < height; y++) {
-            memcpy(da + (size_t)y * width, h_a + (size_t)y * stride, width);
-            memcpy(db + (size_t)y * width, h_b + (size_t)y * stride, width);
+        if (need > c->d_img_cap) {
+            // only ever happens on the first job of a batch (all jobs of a batch have one size)
+            TW_HIP(e, hipStreamSynchronize(e->copy_stream));
+            if (c->d_img) (void)hipFree(c->d_img);
+            c->d_img = nullptr;
+            c->d_img_cap = 0;
+            TW_HIP(e, hipMalloc((void**)&c->d_img, need + 256));
+            c->d_img_cap = need;
         }
-        jb.h_a = da;
-        jb.h_b = db;
+        uint8_t* dst_a = c->d_img + npx * (2 * j);
+        uint8_t* dst_b = c->d_img + npx * (2 * j + 1);
+        if (host_pinned(h_a) && host_pinned(h_b)) {
+            // page-locked caller memory (tw_host_alloc or hipHostRegister): DMA straight from it.  The caller keeps
+            // the buffers unchanged until tw_wait() of this ticket returns.
+            TW_HIP(e, hipMemcpy2DAsync(dst_a, (size_t)width, h_a, (size_t)stride, (size_t)width, (size_t)height,
+                                       hipMemcpyHostToDevice, e->copy_stream));
+            TW_HIP(e, hipMemcpy2DAsync(dst_b, (size_t)width, h_b, (size_t)stride, (size_t)width, (size_t)height,
+                                       hipMemcpyHostToDevice, e->copy_stream));
+        } else {
+            if (need > c->h_img_cap) {
+                if (c->h_img) (void)hipHostFree(c->h_img);
+                c->h_img = nullptr;
+                c->h_img_cap = 0;
+                TW_HIP(e, hipHostMalloc((void**)&c->h_img, need, hipHostMallocDefault));
+                c->h_img_cap = need;
+            }
+            uint8_t* da = c->h_img + npx * (2 * j);
+            uint8_t* db = c->h_img + npx * (2 * j + 1);
+            for (int y = 0; y < height; y++) {
+                memcpy(da + (size_t)y * width, h_a + (size_t)y * stride, width);
+                memcpy(db + (size_t)y * width, h_b + (size_t)y * stride, width);
+            }
+            // both images of the pair in one transfer, queued now: it overlaps the caller's next submit and
+            // whatever the compute stream is still doing for the previous batch
+            TW_HIP(e, hipMemcpyAsync(dst_a, da, npx * 2, hipMemcpyHostToDevice, e->copy_stream));
+        }
+        jb.h_a = h_a;
+        jb.h_b = h_b;
         c->any_host = true;
     } else {
         jb.d_a = (const uint8_t*)d_a;
@@ -1102,6 +1133,7 @@ tw_status tw_engine_create(int device, const tw_params* params, int slots, tw_en
     if (const char* ev = getenv("TW_LANES")) e->lanes = std::min(2, std::max(1, atoi(ev)));
     bool ok = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) == hipSuccess &&
               hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking) == hipSuccess &&
               hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) == hipSuccess &&
               hipMalloc((void**)&e->d_ptrs, sizeof(void*) * 2 * slots + 256) == hipSuccess &&
@@ -1109,6 +1141,7 @@ tw_status tw_engine_create(int device, const tw_params* params, int slots, tw_en
     for (Ctx& c : e->ctx) {
         ok = ok && hipEventCreate(&c.ev_start) == hipSuccess && hipEventCreate(&c.ev_stop) == hipSuccess &&
              hipEventCreateWithFlags(&c.ev_done, hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&c.ev_h2d, hipEventDisableTiming) == hipSuccess &&
              hipHostMalloc((void**)&c.h_ptrs, sizeof(void*) * 2 * slots, hipHostMallocDefault) == hipSuccess &&
              hipHostMalloc((void**)&c.h_count, sizeof(int) * slots, hipHostMallocDefault) == hipSuccess &&
              hipHostMalloc((void**)&c.h_rec, sizeof(ScanRec) * HOST_RECS * (size_t)slots, hipHostMallocDefault) ==
@@ -1133,7 +1166,6 @@ void tw_engine_destroy(tw_engine* e)
     if (e->M[1]) (void)hipFree(e->M[1]);
     for (float* f : e->flow)
         if (f) (void)hipFree(f);
-    if (e->d_img) (void)hipFree(e->d_img);
     if (e->d_ptrs) (void)hipFree((void*)e->d_ptrs);
     if (e->d_count) (void)hipFree(e->d_count);
     if (e->d_rec) (void)hipFree(e->d_rec);
@@ -1141,6 +1173,8 @@ void tw_engine_destroy(tw_engine* e)
     if (e->Vd) (void)hipFree(e->Vd);
     for (Ctx& c : e->ctx) {
         if (c.h_img) (void)hipHostFree(c.h_img);
+        if (c.d_img) (void)hipFree(c.d_img);
+        if (c.ev_h2d) (void)hipEventDestroy(c.ev_h2d);
         if (c.h_ptrs) (void)hipHostFree((void*)c.h_ptrs);
         if (c.h_count) (void)hipHostFree(c.h_count);
         if (c.h_rec) (void)hipHostFree(c.h_rec);
@@ -1150,6 +1184,7 @@ void tw_engine_destroy(tw_engine* e)
     }
     if (e->stream) (void)hipStreamDestroy(e->stream);
     if (e->stream2) (void)hipStreamDestroy(e->stream2);
+    if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     if (e->ev_join) (void)hipEventDestroy(e->ev_join);
     for (auto& kv : e->plans) free_plan(kv.second);
@@ -1295,6 +1330,22 @@ tw_status tw_dev_upload(tw_engine* e, void* dptr, const void* host, size_t bytes
     if (!e || !dptr || !host) return TW_E_BAD_PARAMETER;
     TW_HIP(e, hipSetDevice(e->device));
     TW_HIP(e, hipMemcpy(dptr, host, bytes, hipMemcpyHostToDevice));
+    return TW_OK;
+}
+
+tw_status tw_host_alloc(tw_engine* e, size_t bytes, void** hptr)
+{
+    if (!e || !hptr) return TW_E_BAD_PARAMETER;
+    TW_HIP(e, hipSetDevice(e->device));
+    TW_HIP(e, hipHostMalloc(hptr, bytes, hipHostMallocDefault));
+    return TW_OK;
+}
+tw_status tw_host_free(tw_engine* e, void* hptr)
+{
+    if (!e) return TW_E_BAD_PARAMETER;
+    TW_HIP(e, hipSetDevice(e->device));
+    TW_HIP(e, hipStreamSynchronize(e->copy_stream));  // an upload may still be reading it
+    TW_HIP(e, hipHostFree(hptr));
     return TW_OK;
 }
 
