@@ -35,7 +35,7 @@ def main():
         rows.append((k[0], k[1], nf[k], rd, wr))
     rows.sort(key=lambda r: -(r[3] + r[4]) * r[2])
     # threads per PAIR of one level-0 launch at 1920x1080 (to turn a grid size into pairs per launch)
-    per_pair = {"tw_blur_solve": 9 * 135 * 256, "tw_polyexp": 2 * 8 * 135 * 256, "tw_update_matrices": 30 * 270 * 256,
+    per_pair = {"tw_blur_solve": 9 * 135 * 256, "tw_polyexp": 2 * 8 * 135 * 256, "tw_update_matrices": 30 * 135 * 256,
                 "tw_pyr_level": 2 * 8 * 135 * 256, "tw_span_scan": 1024}
     out = {}
     for prefix, name in NAMES.items():
