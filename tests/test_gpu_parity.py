@@ -260,6 +260,49 @@ def test_config5_parameters_reduced_size(twflow, oracle):
     assert_same(gy, wy, "config-5 flowy")
 
 
+def test_tiny_and_random_shapes_and_parameters(twflow, oracle):
+    """Degenerate sizes (1x1, single rows/columns, smaller than every filter window) and seeded random small
+    shapes with random parameters (polyN, winSize, levels, iterations, pyrScale, box/Gaussian): whole flow field
+    bit for bit, hits identical."""
+    rng = np.random.default_rng(20141121)
+    cases = [((1, 1), {}), ((1, 5), {}), ((5, 1), {}), ((2, 3), {}), ((3, 2), {}), ((7, 5), {}), ((16, 16), {}),
+             ((31, 200), {}), ((200, 31), {}), ((32, 32), {}), ((33, 33), {}), ((64, 1), {}), ((1, 64), {})]
+    for _ in range(24):
+        h, w = int(rng.integers(1, 90)), int(rng.integers(1, 90))
+        kw = dict(polyN=int(rng.choice([3, 5, 7])), winSize=int(rng.integers(2, 24)),
+                  pyrLevels=int(rng.integers(0, 5)), pyrIterations=int(rng.integers(1, 4)),
+                  pyrScale=float(rng.choice([0.5, 0.6, 0.75])), flags=int(rng.choice([0, 256])),
+                  polySigma=float(rng.choice([1.1, 1.5])))
+        cases.append(((h, w), kw))
+    for (h, w), kw in cases:
+        a = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        b = a.copy()
+        if h > 2 and w > 2:
+            b = np.roll(a, (int(rng.integers(-2, 3)), int(rng.integers(-2, 3))), axis=(0, 1))
+        b = np.clip(b.astype(np.int16) + rng.integers(-3, 4, (h, w)), 0, 255).astype(np.uint8)
+        wx, wy = oracle.farneback(a, b, oracle.default_params(**kw))
+        with twflow.Engine(0, twflow.default_params(**kw), slots=1) as e:
+            gx, gy, _ = e.calculate_internal(a, b)
+            r = e.diff(a, b, 3, 0.5)
+        assert_same(gx, wx, "flowx %dx%d %r" % (w, h, kw))
+        assert_same(gy, wy, "flowy %dx%d %r" % (w, h, kw))
+        assert r["vector"] == oracle.span_scan(wx, wy, 3, 0.5), (h, w, kw)
+
+
+@pytest.mark.parametrize("h,w", [(9, 223), (8, 224), (17, 225), (24, 449), (65, 481), (16, 97), (41, 96),
+                                 (72, 671), (73, 673), (128, 1921)])
+def test_tile_boundary_shapes(engine, oracle, h, w):
+    """Sizes one short of, equal to and one past the tile widths / heights of the kernels (224- and 96-column blur
+    tiles, 240-column polyexp tiles, 64x8 update tiles, 256-column pyramid tiles), default parameters."""
+    rng = np.random.default_rng(h * 10007 + w)
+    a = rand_img(rng, h, w)
+    b = np.roll(a, (1, -2), axis=(0, 1))
+    gx, gy, _ = engine.calculate_internal(a, b)
+    wx, wy = oracle.farneback(a, b)
+    assert_same(gx, wx, "flowx %dx%d" % (w, h))
+    assert_same(gy, wy, "flowy %dx%d" % (w, h))
+
+
 def test_pinned_and_pageable_callers_agree(twflow, oracle):
     """tw_submit_u8 from page-locked caller memory (DMA straight from it, also with a row stride) and from
     ordinary memory (staged) — same hits as the oracle; batches overlap on the copy stream."""
