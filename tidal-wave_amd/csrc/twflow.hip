@@ -715,6 +715,7 @@ void launch_blur(tw_engine* e, hipStream_t st, int w, int h, int ld, long long p
     a.ps = ps;
     a.fps = ps;
     a.update = update;
+    a.xsh = 0;
     a.m = e->win_m;
     a.c = e->wc;
     const int gy = (h + BS_TH - 1) / BS_TH;
@@ -766,8 +767,11 @@ void launch_blur(tw_engine* e, hipStream_t st, int w, int h, int ld, long long p
         if (wide) hipLaunchKernelGGL((tw_blur_solve8<15, 256, 16, 8, true, true>), dim3((w + 223) / 224, gy, npairs), dim3(256), 0, st, a);
         else hipLaunchKernelGGL((tw_blur_solve8<15, 128, 16, 8, true, true>), dim3((w + 95) / 96, gy, npairs), dim3(128), 0, st, a);
     } else if (e->win_m == 15) {
-        if (wide) hipLaunchKernelGGL((tw_blur_solve4<15, 256, 16, 8, true>), dim3((w + 223) / 224, gy, npairs), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((tw_blur_solve4<15, 128, 16, 8, true>), dim3((w + 95) / 96, gy, npairs), dim3(128), 0, st, a);
+        // shift the tile grid 16 px left when that costs no extra tile column (see the kernel)
+        const int tw = wide ? 224 : 96;
+        a.xsh = ((w + 16 + tw - 1) / tw == (w + tw - 1) / tw) ? 16 : 0;
+        if (wide) hipLaunchKernelGGL((tw_blur_solve4<15, 256, 16, 8, true>), dim3((w + a.xsh + 223) / 224, gy, npairs), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((tw_blur_solve4<15, 128, 16, 8, true>), dim3((w + a.xsh + 95) / 96, gy, npairs), dim3(128), 0, st, a);
     } else if (e->win_m == 25) {
         // winSize 50/51 (BASELINE config 5): packed-f32 structure, single 58-row register window
         if (wide) hipLaunchKernelGGL((tw_blur_solve8<25, 256, 32, 8, true, false>), dim3((w + 191) / 192, gy, npairs), dim3(256), 0, st, a);

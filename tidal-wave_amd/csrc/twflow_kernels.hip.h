@@ -989,6 +989,7 @@ struct BlurArgs {
     int w, h, ld;
     long long ps, fps;
     int update;  // refresh M (i < iterations-1)
+    int xsh;     // tw_blur_solve4: the tile grid starts this many pixels left of the image
     int m;       // runtime m for the generic kernel
     WinCoef c;
 };
@@ -1010,7 +1011,9 @@ __global__ __launch_bounds__(COLS) void tw_blur_solve4(BlurArgs a)
     const int tid = threadIdx.x;
     int bx, by, z;
     xcd_remap(bx, by, z);
-    const int x0 = bx * TW, y0 = by * TH;
+    // the tile grid starts XSH pixels left of the image so that a wave's 256-byte row segment (which begins HALO
+    // pixels left of its tile) is 128-byte aligned: two cache lines per load instead of three
+    const int x0 = bx * TW - a.xsh, y0 = by * TH;
     const WinCoef& c = a.c;
     const float* __restrict__ Min = a.Min + (long long)z * 5 * a.ps;
     float* __restrict__ flow = a.flow + (long long)z * 2 * a.fps;
@@ -1105,8 +1108,8 @@ __global__ __launch_bounds__(COLS) void tw_blur_solve4(BlurArgs a)
     for (int p = tid; p < TH * TW; p += COLS) {
         const int r = p / TW, cx = p - r * TW;
         const int x = x0 + cx, y = y0 + r;
-        const bool valid = x < a.w && y < a.h;
-        const int xc = min(x, a.w - 1), yc = min(y, a.h - 1);
+        const bool valid = x >= 0 && x < a.w && y < a.h;
+        const int xc = clampi(x, 0, a.w - 1), yc = min(y, a.h - 1);
         const double g11 = sm[0][r][HALO + cx], g12 = sm[1][r][HALO + cx], g22 = sm[2][r][HALO + cx],
                      h1 = sm[3][r][HALO + cx], h2 = sm[4][r][HALO + cx];
         const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
