@@ -169,6 +169,24 @@ def main():
     if rank == 0:
         value = pairs_total / elapsed
         bytes_pair = eng.algorithmic_bytes_pair(W, H, SPAN)
+        # measured device copy rate of this GPU in this run (report it beside the 8 TB/s nominal peak):
+        # 1 GiB torch copy, read + write counted, outside the timed region
+        copy_gbs = None
+        try:
+            src = torch.empty(1 << 30, dtype=torch.uint8, device=torch.device("cuda", dev_index))
+            dst = torch.empty_like(src)
+            dst.copy_(src)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                dst.copy_(src)
+            e1.record()
+            torch.cuda.synchronize()
+            copy_gbs = round(2 * 10 * (1 << 30) / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+            del src, dst
+        except Exception:
+            copy_gbs = None
         traffic = {}
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tpath):
@@ -213,9 +231,12 @@ def main():
                        "batch_per_gpu": args.batch, "engine_batch": args.slots,
                        "parallelism": "pairs sharded over %d GPU(s), no collective" % world,
                        "single_pair_latency_ms": round(float(np.median(lat)) * 1e3, 4)},
+            "measured_copy_GBps": copy_gbs,
             "pair_roofline": {"algorithmic_bytes_per_pair": bytes_pair,
                               "achieved_GBps_per_gpu": round(bytes_pair * value / world / 1e9, 1),
-                              "frac_of_8TBps": round(bytes_pair * value / world / 1e9 / HBM_PEAK_GBS, 4)},
+                              "frac_of_8TBps": round(bytes_pair * value / world / 1e9 / HBM_PEAK_GBS, 4),
+                              "frac_of_measured_copy": round(bytes_pair * value / world / 1e9 / copy_gbs, 4)
+                              if copy_gbs else None},
             "roofline": roof(twflow.K_BLUR_SOLVE),
             "roofline_polyexp": roof(twflow.K_POLYEXP),
             "flagged_vectors": flagged_total,
