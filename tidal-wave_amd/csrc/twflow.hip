@@ -425,7 +425,9 @@ tw_status get_plan(tw_engine* e, int w0, int h0, Plan** out)
         L.ps = (long long)L.ld * L.h;
         // pairs per launch: enough 8-row x 240-column tiles of two images to cover the 256 CUs many times over
         const long long tiles = (long long)((L.w + PE_TW - 1) / PE_TW) * ((L.h + PE_TH - 1) / PE_TH) * 2;
-        long long target = 16384;  // measured: 4096 -> 16384 tiles per launch is +11 % pairs/s at 1080p (fewer tails and gaps)
+        // measured at 1080p: 4096 -> 16384 tiles per launch is +11 % pairs/s (fewer tails and gaps), 16384 -> 34000
+        // (16 pairs per level-0 launch: 19440 blur workgroups = 18.98 rounds of the 1024 resident ones) another +2.5 %
+        long long target = 34000;
         if (const char* ev = getenv("TW_CHUNK_TILES")) target = std::max(1, atoi(ev));
         long long c = (target + tiles - 1) / tiles;
         L.chunk = (int)std::min<long long>(std::max<long long>(c, 1), e->cap);
