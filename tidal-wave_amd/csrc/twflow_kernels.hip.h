@@ -557,28 +557,65 @@ __device__ __forceinline__ void pyr_load_row(const uint8_t* __restrict__ S, int 
     }
 }
 
+// own = the lane's aligned u8 word(s) of a row; the byte left of them comes from lane-1's last word and the byte
+// right of them from lane+1's first word (DPP wave shifts) — every source byte is requested from memory once
+// instead of three times.  Wave edges, row ends and unaligned images fall back to byte loads (REFLECT101).
+__device__ __forceinline__ unsigned dpp_from_prev(unsigned v)
+{
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false);  // wave_shr:1
+}
+__device__ __forceinline__ unsigned dpp_from_next(unsigned v)
+{
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, false);  // wave_shl:1
+}
+
 template <int MODE>
 __global__ __launch_bounds__(256) void tw_pyr_k3(PyrK3Args a)
 {
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // tx = lane: a wave is 64 consecutive 4-pixel groups
     const int ox = (blockIdx.x * 64 + tx) * 4;
     const uint8_t* __restrict__ src = a.srcs[blockIdx.z];
     float* __restrict__ dst = a.dst + blockIdx.z * a.dst_zs;
-    if (ox >= a.w) return;
+    const bool in_w = ox < a.w;  // lanes past the row end stay active for the lane exchange, they only skip memory
     const float k0 = a.k0, k1 = a.k1;
     if (MODE == 0) {
         const int oy = (blockIdx.y * 4 + ty) * 2;
-        if (oy >= a.h) return;
-        const bool fast = a.aligned4 && ox >= 4 && ox + 8 <= a.w0;
+        if (oy >= a.h) return;  // wave-uniform
+        const bool own_ok = a.aligned4 && ox + 3 < a.w0;
+        const bool left_ok = tx > 0 && a.aligned4 && ox - 1 < a.w0;
+        const bool right_ok = tx < 63 && a.aligned4 && ox + 7 < a.w0;
         float rf[4][4];
+        // all loads of the four rows first (own word, plus the edge bytes of the lanes that have no neighbour)
+        unsigned own[4], lb[4], rb[4];
+        const bool need_l = in_w && !left_ok, need_r = in_w && !right_ok, need_own = in_w && !own_ok;
 #pragma unroll
         for (int rr = 0; rr < 4; rr++) {
             const int Y = reflect101(oy - 1 + rr, a.h0);
+            const uint8_t* __restrict__ S = src + (long long)Y * a.stride;
+            own[rr] = 0;
+            lb[rr] = rb[rr] = 0;
+            if (own_ok) own[rr] = *(const unsigned*)(S + ox);
+            if (need_l) lb[rr] = S[reflect101(ox - 1, a.w0)];
+            if (need_r) rb[rr] = S[reflect101(ox + 4, a.w0)];
+            if (need_own) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) own[rr] |= (unsigned)S[reflect101(ox + j, a.w0)] << (8 * j);
+            }
+        }
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++) {
+            const unsigned lw = dpp_from_prev(own[rr]), rw = dpp_from_next(own[rr]);
             float v[6];
-            pyr_load_row<6>(src + (long long)Y * a.stride, ox - 1, a.w0, fast, v);
+            v[0] = need_l ? (float)lb[rr] : (float)(lw >> 24);
+            v[1] = (float)(own[rr] & 0xffu);
+            v[2] = (float)((own[rr] >> 8) & 0xffu);
+            v[3] = (float)((own[rr] >> 16) & 0xffu);
+            v[4] = (float)(own[rr] >> 24);
+            v[5] = need_r ? (float)rb[rr] : (float)(rw & 0xffu);
 #pragma unroll
             for (int j = 0; j < 4; j++) rf[rr][j] = v[j + 1] * k0 + (v[j] + v[j + 2]) * k1;
         }
+        if (!in_w) return;
 #pragma unroll
         for (int q = 0; q < 2; q++) {
             if (oy + q >= a.h) break;
@@ -593,18 +630,49 @@ __global__ __launch_bounds__(256) void tw_pyr_k3(PyrK3Args a)
         }
     } else {
         const int oy = blockIdx.y * 4 + ty;
-        if (oy >= a.h) return;
+        if (oy >= a.h) return;  // wave-uniform
         const int sx = 2 * ox;  // first source column of the 8 blurred samples
-        const bool fast = a.aligned4 && sx >= 4 && sx + 12 <= a.w0;
+        const bool own_ok = a.aligned4 && sx + 7 < a.w0;
+        const bool left_ok = tx > 0 && a.aligned4 && sx - 1 < a.w0;
+        const bool right_ok = tx < 63 && a.aligned4 && sx + 15 < a.w0;
         float rf[4][8];
+        unsigned o0[4], o1[4], lb[4], rb[4];
+        const bool need_l = in_w && !left_ok, need_r = in_w && !right_ok, need_own = in_w && !own_ok;
 #pragma unroll
         for (int rr = 0; rr < 4; rr++) {
             const int Y = reflect101(2 * oy - 1 + rr, a.h0);
+            const uint8_t* __restrict__ S = src + (long long)Y * a.stride;
+            o0[rr] = o1[rr] = lb[rr] = rb[rr] = 0;
+            if (own_ok) {
+                const u32x2 w2 = *(const u32x2*)(S + sx);
+                o0[rr] = w2.x;
+                o1[rr] = w2.y;
+            }
+            if (need_l) lb[rr] = S[reflect101(sx - 1, a.w0)];
+            if (need_r) rb[rr] = S[reflect101(sx + 8, a.w0)];
+            if (need_own) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    o0[rr] |= (unsigned)S[reflect101(sx + j, a.w0)] << (8 * j);
+                    o1[rr] |= (unsigned)S[reflect101(sx + 4 + j, a.w0)] << (8 * j);
+                }
+            }
+        }
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++) {
+            const unsigned lw = dpp_from_prev(o1[rr]), rw = dpp_from_next(o0[rr]);
             float v[10];
-            pyr_load_row<10>(src + (long long)Y * a.stride, sx - 1, a.w0, fast, v);
+            v[0] = need_l ? (float)lb[rr] : (float)(lw >> 24);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                v[1 + j] = (float)((o0[rr] >> (8 * j)) & 0xffu);
+                v[5 + j] = (float)((o1[rr] >> (8 * j)) & 0xffu);
+            }
+            v[9] = need_r ? (float)rb[rr] : (float)(rw & 0xffu);
 #pragma unroll
             for (int j = 0; j < 8; j++) rf[rr][j] = v[j + 1] * k0 + (v[j] + v[j + 2]) * k1;
         }
+        if (!in_w) return;
         float o[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) {
