@@ -303,6 +303,36 @@ def test_tile_boundary_shapes(engine, oracle, h, w):
     assert_same(gy, wy, "flowy %dx%d" % (w, h))
 
 
+def test_two_engines_on_two_threads(twflow, oracle):
+    """Engines are per-thread objects; different engines may run concurrently from different threads on one
+    device (SURVEY §8b threading row).  Both produce the oracle's hits."""
+    import threading
+    import synth
+    pairs = [synth.make_pair(i, 240, 320) for i in range(4)]
+    want = []
+    for a, b in pairs:
+        wx, wy = oracle.farneback(a, b)
+        want.append(oracle.span_scan(wx, wy, 10, 5.0))
+    out = {}
+
+    def work(tid):
+        with twflow.Engine(0, twflow.default_params(), slots=4) as e:
+            got = []
+            for rep in range(5):
+                tk = [e.submit(a, b) for a, b in pairs]
+                got.append([e.wait(t)["vector"] for t in tk])
+            out[tid] = got
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for tid in range(2):
+        for got in out[tid]:
+            assert got == want
+
+
 def test_pinned_and_pageable_callers_agree(twflow, oracle):
     """tw_submit_u8 from page-locked caller memory (DMA straight from it, also with a row stride) and from
     ordinary memory (staged) — same hits as the oracle; batches overlap on the copy stream."""
