@@ -227,6 +227,26 @@ def test_scan_many_hits_and_dense_span(twflow, oracle):
             assert got == want
 
 
+def test_many_hits_survive_later_batches(twflow, oracle):
+    """Three batches in flight, each pair with more hits than the eager copy (1024 records): the late tw_wait of
+    the first batch still returns every record (one record region per batch context)."""
+    rng = np.random.default_rng(8)
+    imgs = []
+    for k in range(3):
+        a = rand_img(rng, 120, 160)
+        imgs.append((a, np.roll(a, 2 + k, axis=1)))
+    want = []
+    for a, b in imgs:
+        wx, wy = oracle.farneback(a, b)
+        want.append(oracle.span_scan(wx, wy, 1, 0.25))
+        assert len(want[-1]) > 1024
+    with twflow.Engine(0, twflow.default_params(), slots=1) as e:
+        tk = [e.submit(a, b, 1, 0.25) for a, b in imgs]   # slots=1: every submit is its own batch
+        e.flush()
+        for i in (2, 0, 1):
+            assert e.wait(tk[i])["vector"] == want[i]
+
+
 @pytest.mark.parametrize("kw", [dict(polyN=5, polySigma=1.1), dict(winSize=50, pyrIterations=2),
                                 dict(winSize=13, pyrIterations=1), dict(pyrLevels=0), dict(pyrLevels=1, pyrIterations=4),
                                 dict(pyrScale=0.8, pyrLevels=3), dict(pyrScale=0.6, pyrLevels=2, polyN=3)])

@@ -258,6 +258,10 @@ struct Ctx {
     uint8_t* d_img = nullptr;
     size_t d_img_cap = 0;
     hipEvent_t ev_h2d = nullptr;
+    // ordered hit records of the batch [cap][G]: tw_wait reads them late when a pair has more than HOST_RECS hits,
+    // so they belong to the context, not to the engine (a later batch must not overwrite them)
+    ScanRec* d_rec = nullptr;
+    size_t d_rec_cap = 0;
     // pinned host memory
     uint8_t* h_img = nullptr;
     size_t h_img_cap = 0;
@@ -305,9 +309,8 @@ struct tw_engine {
     hipStream_t copy_stream = nullptr;  // host -> device image uploads, overlapped with the compute stream
     const uint8_t** d_ptrs = nullptr;  // [2*cap]
     int* d_count = nullptr;            // [cap]
-    ScanRec* d_rec = nullptr;          // [cap][G]
     float2* d_grid = nullptr;          // [cap][G] dense grid samples (dx,dy)
-    size_t d_rec_cap = 0;
+    size_t d_grid_cap = 0;
     // profiling: per kernel class, -2 = off, -1 = every level, k = level k only
     int prof_level[TW_K_COUNT] = {-2, -2, -2, -2, -2};
     std::vector<ProfPair> prof_pending[TW_K_COUNT];
@@ -508,7 +511,7 @@ tw_status reserve_workspace(tw_engine* e, const Plan* pl, int span, bool need_im
         }
     (void)need_img;  // image regions belong to the batch contexts (submit_common)
     const size_t G = span > 0 ? (size_t)tw_grid_capacity(pl->w0, pl->h0, span) : 0;
-    if (G * e->cap > e->d_rec_cap) grow = true;
+    if (G * e->cap > e->d_grid_cap) grow = true;
     if (!grow) return TW_OK;
     TW_HIP(e, hipStreamSynchronize(e->stream));
     TW_HIP(e, hipStreamSynchronize(e->stream2));
@@ -546,15 +549,12 @@ tw_status reserve_workspace(tw_engine* e, const Plan* pl, int span, bool need_im
             e->flow_cap[k] = fc;
         }
     }
-    if (G * e->cap > e->d_rec_cap) {
-        if (e->d_rec) (void)hipFree(e->d_rec);
+    if (G * e->cap > e->d_grid_cap) {
         if (e->d_grid) (void)hipFree(e->d_grid);
-        e->d_rec = nullptr;
         e->d_grid = nullptr;
-        e->d_rec_cap = 0;
+        e->d_grid_cap = 0;
         TW_HIP(e, hipMalloc((void**)&e->d_grid, G * e->cap * sizeof(float2) + 256));
-        TW_HIP(e, hipMalloc((void**)&e->d_rec, G * e->cap * sizeof(ScanRec) + 256));
-        e->d_rec_cap = G * e->cap;
+        e->d_grid_cap = G * e->cap;
     }
     return TW_OK;
 }
@@ -830,6 +830,17 @@ tw_status flush_ctx(tw_engine* e, Ctx& c)
     tw_status r = get_plan(e, c.w, c.h, &pl);
     if (r) return r;
     if ((r = reserve_workspace(e, pl, c.span, c.any_host))) return r;
+    if (c.span > 0) {
+        const size_t need_rec = (size_t)tw_grid_capacity(c.w, c.h, c.span) * e->cap;
+        if (need_rec > c.d_rec_cap) {
+            // this context has no results outstanding (it is being launched), nothing on the stream uses its records
+            if (c.d_rec) (void)hipFree(c.d_rec);
+            c.d_rec = nullptr;
+            c.d_rec_cap = 0;
+            TW_HIP(e, hipMalloc((void**)&c.d_rec, need_rec * sizeof(ScanRec) + 256));
+            c.d_rec_cap = need_rec;
+        }
+    }
     const int n = (int)c.jobs.size();
     const size_t npx = staged_image_bytes(c.w, c.h);  // staged images are 256-byte aligned
     long long stride = c.jobs[0].stride;
@@ -914,7 +925,7 @@ tw_status flush_ctx(tw_engine* e, Ctx& c)
         a.thr2 = c.threshold * c.threshold;
         a.count = e->d_count;
         a.rec_zs = (long long)a.gw * a.gh;
-        a.rec = e->d_rec;
+        a.rec = c.d_rec;
         ProfScope pscope(e, st, TW_K_SCAN, 0);
         hipLaunchKernelGGL(tw_span_scan, dim3(n), dim3(1024), 0, st, a);
     }
@@ -923,7 +934,7 @@ tw_status flush_ctx(tw_engine* e, Ctx& c)
         const size_t G = (size_t)tw_grid_capacity(c.w, c.h, c.span);
         const size_t nrec = std::min((size_t)HOST_RECS, G);
         TW_HIP(e, hipMemcpyAsync(c.h_count, e->d_count, sizeof(int) * n, hipMemcpyDeviceToHost, st));
-        TW_HIP(e, hipMemcpy2DAsync(c.h_rec, HOST_RECS * sizeof(ScanRec), e->d_rec, G * sizeof(ScanRec),
+        TW_HIP(e, hipMemcpy2DAsync(c.h_rec, HOST_RECS * sizeof(ScanRec), c.d_rec, G * sizeof(ScanRec),
                                    nrec * sizeof(ScanRec), n, hipMemcpyDeviceToHost, st));
     }
     TW_HIP(e, hipGetLastError());
@@ -1174,12 +1185,12 @@ void tw_engine_destroy(tw_engine* e)
         if (f) (void)hipFree(f);
     if (e->d_ptrs) (void)hipFree((void*)e->d_ptrs);
     if (e->d_count) (void)hipFree(e->d_count);
-    if (e->d_rec) (void)hipFree(e->d_rec);
     if (e->d_grid) (void)hipFree(e->d_grid);
     if (e->Vd) (void)hipFree(e->Vd);
     for (Ctx& c : e->ctx) {
         if (c.h_img) (void)hipHostFree(c.h_img);
         if (c.d_img) (void)hipFree(c.d_img);
+        if (c.d_rec) (void)hipFree(c.d_rec);
         if (c.ev_h2d) (void)hipEventDestroy(c.ev_h2d);
         if (c.h_ptrs) (void)hipHostFree((void*)c.h_ptrs);
         if (c.h_count) (void)hipHostFree(c.h_count);
@@ -1261,11 +1272,11 @@ tw_status tw_wait(tw_engine* e, tw_ticket ticket, tw_vector* out, int cap, int* 
         const ScanRec* hr = c->h_rec + (size_t)j * HOST_RECS;
         std::vector<ScanRec> extra;
         if (want > HOST_RECS && out) {
-            // rare: more hits than the eager copy holds.  The device records are intact as long as no
-            // later batch of this engine has been flushed.
+            // rare: more hits than the eager copy holds; the batch context's own record region still has them
             const size_t G = (size_t)tw_grid_capacity(c->w, c->h, c->span);
             extra.resize(want);
-            TW_HIP(e, hipMemcpy(extra.data(), e->d_rec + (size_t)j * G, (size_t)want * sizeof(ScanRec),
+            TW_HIP(e, hipMemcpy(extra.data(), c->d_rec + (size_t)j * G,
+                                (size_t)want * sizeof(ScanRec),
                                 hipMemcpyDeviceToHost));
             hr = extra.data();
         }
