@@ -73,6 +73,10 @@ def cpu_baseline(pairs):
             fx, fy = O.farneback(a, b)  # ctypes releases the GIL
             out[j] = O.span_scan(fx, fy, SPAN, THRESHOLD)
 
+    # one pair on one thread first (the reference's per-call cost: OpenCV 2.4.9's Farneback is single-threaded)
+    t1 = time.perf_counter()
+    O.farneback(*pairs[0])
+    one = time.perf_counter() - t1
     t0 = time.perf_counter()
     th = [threading.Thread(target=work) for _ in range(threads)]
     for t in th:
@@ -81,6 +85,7 @@ def cpu_baseline(pairs):
         t.join()
     dt = time.perf_counter() - t0
     return {"value": njobs / dt, "unit": "pairs/s", "cores": threads, "kind": "port",
+            "single_thread_pairs_per_s": round(1.0 / one, 3),
             "sample": "%d x 1920x1080 synthetic pairs pulled from one queue by %d threads (of %d host cores), %.1f s wall"
                       % (njobs, threads, cores, dt)}, out
 
