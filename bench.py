@@ -165,11 +165,24 @@ def main():
         [flagged[0], args.batch * args.steps])
 
     prof = {}
+    breakdown = None
     if not args.no_prof:
         for kc in (twflow.K_BLUR_SOLVE, twflow.K_POLYEXP):
             ms, n = eng.prof_read(kc)
             prof[kc] = (ms, n)
         eng.prof_select(-1, -2)
+        if rank == 0:
+            # outside the timed region: one more step with every launch of every kernel class bracketed (all
+            # levels) -> where the time of a pair goes
+            classes = (twflow.K_PYR, twflow.K_POLYEXP, twflow.K_UPDATE_MATRICES, twflow.K_BLUR_SOLVE, twflow.K_SCAN)
+            for kc in classes:
+                eng.prof_select(kc, -1)
+            step()
+            breakdown = {}
+            for kc in classes:
+                ms, n = eng.prof_read(kc)
+                breakdown[twflow.KERNEL_NAMES[kc]] = {"us_per_pair": round(ms * 1e3 / args.batch, 2), "launches": n}
+            eng.prof_select(-1, -2)
 
     if rank == 0:
         value = pairs_total / elapsed
@@ -242,6 +255,7 @@ def main():
                               "frac_of_8TBps": round(bytes_pair * value / world / 1e9 / HBM_PEAK_GBS, 4),
                               "frac_of_measured_copy": round(bytes_pair * value / world / 1e9 / copy_gbs, 4)
                               if copy_gbs else None},
+            "kernel_breakdown": breakdown,
             "roofline": roof(twflow.K_BLUR_SOLVE),
             "roofline_polyexp": roof(twflow.K_POLYEXP),
             "flagged_vectors": flagged_total,
