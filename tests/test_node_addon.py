@@ -191,3 +191,58 @@ def test_cli_on_the_golden_pair():
     gold = json.load(open(os.path.join(ROOT, "tests", "golden", "expected_responses.json")))["revision2_capture2"]
     assert docs[0]["status"] == "SUSPICIOUS" and docs[0]["vector"] == gold["vector"]
     assert docs[-1] == {"request": 1, "data": 1, "error": 0}
+
+
+@needs_node
+@pytest.mark.gpu
+def test_many_jobs_mixed_sizes_and_errors_through_the_addon(tmp_path):
+    """80 small PNG pairs of three sizes plus unreadable and mismatching files through new TidalWave().calc():
+    every job ends in exactly one 'data' or 'error' event, the report adds up, and each result equals the
+    oracle's (status and vectors) — the batching consumer must keep tickets and responses straight."""
+    Image = pytest.importorskip("PIL.Image")
+    sys_path_oracle()
+    import oracle as O
+    sys_path = os.path.join(ROOT, "tidal-wave_amd")
+    import sys
+    if sys_path not in sys.path:
+        sys.path.insert(0, sys_path)
+    import synth
+    jobs = []
+    sizes = [(48, 64), (60, 90), (33, 47)]
+    for i in range(80):
+        h, w = sizes[i % 3]
+        a, b = synth.make_pair(i, h, w)
+        pa, pb = tmp_path / ("e%03d.png" % i), tmp_path / ("t%03d.png" % i)
+        Image.fromarray(a).save(pa)
+        Image.fromarray(b).save(pb)
+        jobs.append((str(pa), str(pb), a, b))
+    bad = tmp_path / "broken.png"
+    bad.write_bytes(b"\x89PNG\r\n\x1a\nnot a png at all")
+    big = tmp_path / "big.png"
+    Image.fromarray(np.zeros((200, 200), np.uint8)).save(big)
+    extra = [(str(bad), jobs[0][1]), (jobs[0][0], str(tmp_path / "missing.png")), (jobs[0][0], str(big))]
+    listing = tmp_path / "jobs.json"
+    listing.write_text(json.dumps([[j[0], j[1]] for j in jobs] + [list(x) for x in extra]))
+    r = node("""
+var T=require('./index'); var jobs=JSON.parse(require('fs').readFileSync(process.argv[1]));
+var t=new T.TidalWave({threshold:1.5, span:7, numThreads:4}); var data=[], errors=[];
+t.on('data',function(d){data.push(d); if (data.length+errors.length===jobs.length) t.dispose();});
+t.on('error',function(e){errors.push(e); if (data.length+errors.length===jobs.length) t.dispose();});
+t.on('finish',function(rep){console.log(JSON.stringify({report:rep,data:data,errors:errors}));});
+jobs.forEach(function(j){t.calc(j[0],j[1]);});
+""", str(listing), timeout=300)
+    assert r.returncode == 0, r.stderr[-500:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["report"] == {"request": 83, "data": 80, "error": 3}
+    reasons = sorted(e["reason"] for e in out["errors"])
+    assert reasons == sorted(["Can't open " + str(bad), "Can't open " + str(tmp_path / "missing.png"),
+                              "Don't match image size"])
+    by_target = {d["target_image"]: d for d in out["data"]}
+    assert len(by_target) == 80
+    for pa, pb, a, b in jobs:
+        d = by_target[pb]
+        wx, wy = O.farneback(a, b)
+        want = O.span_scan(wx, wy, 7, 1.5)
+        assert d["expect_image"] == pa and (d["height"], d["width"]) == a.shape
+        assert d["status"] == ("SUSPICIOUS" if want else "OK")
+        assert [(v["x"], v["y"], v["dx"], v["dy"]) for v in d["vector"]] == [tuple(v) for v in want]

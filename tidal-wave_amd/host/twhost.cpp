@@ -245,6 +245,7 @@ struct Staged {
     std::string err;
     tw_ticket ticket = 0;
     bool submitted = false;
+    bool done = false;  // response pushed
 };
 
 // OpticalFlow::calculate up to (not including) calculateInternal: src/opticalflow.cpp:20-68
@@ -299,15 +300,15 @@ void Consumer::run()
             worker();
             for (std::thread& t : pool) t.join();
         }
-        for (Staged& s : jobs) {
-            if (s.err.empty() && !eng) s.err = eng_err;
-            if (s.err.empty()) {
-                tw_status r = tw_submit_u8(eng, s.a.data(), s.b.data(), s.w, s.h, s.w, s.req.span, s.req.threshold, &s.ticket);
-                if (r == TW_OK) s.submitted = true;
-                else s.err = std::string(tw_last_error(eng)[0] ? tw_last_error(eng) : tw_strerror(r));
-            }
-        }
-        for (Staged& s : jobs) {
+        // one engine batch is homogeneous in size: group equal sizes so that a mixed queue makes few batches
+        // (responses are delivered in completion order anyway, like the reference's)
+        std::stable_sort(jobs.begin(), jobs.end(), [](const Staged& x, const Staged& y) {
+            return x.w != y.w ? x.w < y.w : x.h < y.h;
+        });
+        // wait for one job and hand its response to the pump
+        auto finish = [&](Staged& s) {
+            if (s.done) return;
+            s.done = true;
             Response res;
             if (s.submitted) {
                 const int cap = std::max(1, tw_grid_capacity(s.w, s.h, s.req.span));
@@ -336,7 +337,22 @@ void Consumer::run()
                 res.reason = s.err;
             }
             res_.push(std::move(res));
+        };
+        for (size_t k = 0; k < jobs.size(); k++) {
+            Staged& s = jobs[k];
+            if (s.err.empty() && !eng) s.err = eng_err;
+            if (!s.err.empty()) continue;
+            tw_status r = tw_submit_u8(eng, s.a.data(), s.b.data(), s.w, s.h, s.w, s.req.span, s.req.threshold, &s.ticket);
+            if (r == TW_E_BUSY) {
+                // every batch context of the engine is owed to us (each size change opens one): collect what
+                // is outstanding, then this job starts a fresh batch
+                for (size_t q = 0; q < k; q++) finish(jobs[q]);
+                r = tw_submit_u8(eng, s.a.data(), s.b.data(), s.w, s.h, s.w, s.req.span, s.req.threshold, &s.ticket);
+            }
+            if (r == TW_OK) s.submitted = true;
+            else s.err = std::string(tw_last_error(eng)[0] ? tw_last_error(eng) : tw_strerror(r));
         }
+        for (Staged& s : jobs) finish(s);
     }
     if (eng) tw_engine_destroy(eng);
 }
