@@ -83,6 +83,75 @@ def decode_gray(path, out):
     return np.fromfile(out, np.uint8).reshape(h, w)
 
 
+def _png_chunk(tag, data):
+    import struct
+    import zlib
+    return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xffffffff)
+
+
+def _write_png(path, arr, interlace, depth=8):
+    """Minimal PNG writer (filter 0 rows) for 8-bit gray / RGB / RGBA arrays, optionally Adam7-interlaced."""
+    import struct
+    import zlib
+    h, w = arr.shape[:2]
+    ch = 1 if arr.ndim == 2 else arr.shape[2]
+    ctype = {1: 0, 3: 2, 4: 6}[ch]
+    a3 = arr.reshape(h, w, ch)
+    raw = b""
+    if interlace:
+        for x0, y0, dx, dy in ((0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2)):
+            sub = a3[y0::dy, x0::dx]
+            if sub.shape[0] and sub.shape[1]:
+                raw += b"".join(b"\x00" + sub[y].tobytes() for y in range(sub.shape[0]))
+    else:
+        raw = b"".join(b"\x00" + a3[y].tobytes() for y in range(h))
+    ihdr = struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, 1 if interlace else 0)
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + _png_chunk(b"IHDR", ihdr) + _png_chunk(b"IDAT", zlib.compress(raw, 6)) +
+                _png_chunk(b"IEND", b""))
+
+
+@needs_node
+def test_png_variants_interlaced_palette_16bit(tmp_path):
+    """Adam7-interlaced gray / RGB / RGBA files (sizes that leave some passes empty), palette and 16-bit files:
+    the host decode equals libpng-1.5's gray conversion of what PIL (libpng) reads from the same file."""
+    Image = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(12)
+
+    def gray15(rgb):
+        r, g, b = (rgb[..., i].astype(np.int64) for i in range(3))
+        v = ((9797 * r + 19234 * g + 3737 * b) >> 15).astype(np.uint8)
+        same = (r == g) & (g == b)
+        return np.where(same, r.astype(np.uint8), v)
+
+    n = 0
+    for (h, w) in ((1, 1), (3, 2), (5, 9), (16, 16), (37, 53)):
+        for ch in (1, 3, 4):
+            arr = rng.integers(0, 256, (h, w) if ch == 1 else (h, w, ch), dtype=np.uint8)
+            for inter in (False, True):
+                p = tmp_path / ("v_%dx%d_c%d_i%d.png" % (w, h, ch, inter))
+                _write_png(p, arr, inter)
+                pil = np.asarray(Image.open(p).convert("RGB"))
+                want = arr if ch == 1 else gray15(pil)
+                assert np.array_equal(pil, np.repeat(arr[..., None], 3, -1) if ch == 1 else arr[..., :3])  # valid file
+                got = decode_gray(p, str(p) + ".bin")
+                assert got is not None and np.array_equal(got, want), p.name
+                n += 1
+    # palette (PIL writes mode "P") and 16-bit gray
+    rgb = rng.integers(0, 256, (20, 31, 3), dtype=np.uint8)
+    pim = Image.fromarray(rgb).quantize(17)
+    p = tmp_path / "pal.png"
+    pim.save(p)
+    got = decode_gray(p, str(p) + ".bin")
+    assert np.array_equal(got, gray15(np.asarray(Image.open(p).convert("RGB"))))
+    g16 = rng.integers(0, 65536, (9, 14), dtype=np.uint16)
+    p = tmp_path / "g16.png"
+    Image.fromarray(g16).save(p)
+    got = decode_gray(p, str(p) + ".bin")
+    assert np.array_equal(got, (g16 >> 8).astype(np.uint8))
+    assert n == 30
+
+
 @needs_node
 def test_jpeg_fixture_decode_matches_golden_gray(tmp_path):
     """Host JPEG decode (progressive Huffman, integer IDCT, luma only) of the reference's capture1.jpg == the

@@ -99,7 +99,7 @@ static bool decode_png(const std::vector<uint8_t>& d, std::vector<uint8_t>& img,
         }
         p += 12 + (size_t)len;
     }
-    if (!have_ihdr || w < 1 || h < 1 || w > 32768 || h > 32768 || interlace != 0) return false;
+    if (!have_ihdr || w < 1 || h < 1 || w > 32768 || h > 32768 || interlace > 1) return false;
     int ch;
     switch (ctype) {
         case 0: ch = 1; break;
@@ -112,16 +112,35 @@ static bool decode_png(const std::vector<uint8_t>& d, std::vector<uint8_t>& img,
     if (!(depth == 8 || depth == 16 || ((ctype == 0 || ctype == 3) && (depth == 1 || depth == 2 || depth == 4))))
         return false;
     const size_t bpp_bits = (size_t)ch * depth;
-    const size_t rowbytes = ((size_t)w * bpp_bits + 7) / 8;
     const size_t fbpp = std::max<size_t>(1, bpp_bits / 8);
-    std::vector<uint8_t> raw((rowbytes + 1) * (size_t)h);
+    // Adam7 (interlace 1): seven reduced images one after the other, each with its own filtered rows; a pass is
+    // unfiltered and converted like a whole image and its pixels scattered to (x0 + i*dx, y0 + j*dy)
+    static const int AX0[7] = {0, 4, 0, 2, 0, 1, 0}, AY0[7] = {0, 0, 4, 0, 2, 0, 1};
+    static const int ADX[7] = {8, 8, 4, 4, 2, 2, 1}, ADY[7] = {8, 8, 8, 4, 4, 2, 2};
+    const int npass = interlace ? 7 : 1;
+    size_t total = 0;
+    for (int ps = 0; ps < npass; ps++) {
+        const int pw = interlace ? (w - AX0[ps] + ADX[ps] - 1) / ADX[ps] : w;
+        const int ph = interlace ? (h - AY0[ps] + ADY[ps] - 1) / ADY[ps] : h;
+        if (pw > 0 && ph > 0) total += (((size_t)pw * bpp_bits + 7) / 8 + 1) * (size_t)ph;
+    }
+    std::vector<uint8_t> raw(total);
     uLongf outlen = (uLongf)raw.size();
     if (uncompress(raw.data(), &outlen, idat.data(), (uLong)idat.size()) != Z_OK || outlen != raw.size()) return false;
+    img.resize((size_t)w * h);
+    size_t pass_off = 0;
+    const int W = w, H = h;  // the loops below run over one pass: w/h are its dimensions
+    for (int ps = 0; ps < npass; ps++) {
+    const int x0 = interlace ? AX0[ps] : 0, y0 = interlace ? AY0[ps] : 0;
+    const int dx = interlace ? ADX[ps] : 1, dy = interlace ? ADY[ps] : 1;
+    const int w = interlace ? (W - x0 + dx - 1) / dx : W, h = interlace ? (H - y0 + dy - 1) / dy : H;
+    if (w <= 0 || h <= 0) continue;
+    const size_t rowbytes = ((size_t)w * bpp_bits + 7) / 8;
+    std::vector<uint8_t> line((size_t)w);
     // unfilter in place
     std::vector<uint8_t> prev(rowbytes, 0);
-    img.resize((size_t)w * h);
     for (int y = 0; y < h; y++) {
-        uint8_t* row = &raw[(rowbytes + 1) * (size_t)y];
+        uint8_t* row = &raw[pass_off + (rowbytes + 1) * (size_t)y];
         const int ft = row[0];
         uint8_t* cur = row + 1;
         for (size_t i = 0; i < rowbytes; i++) {
@@ -141,7 +160,7 @@ static bool decode_png(const std::vector<uint8_t>& d, std::vector<uint8_t>& img,
             cur[i] = (uint8_t)v;
         }
         memcpy(prev.data(), cur, rowbytes);
-        uint8_t* out = &img[(size_t)y * w];
+        uint8_t* out = line.data();
         auto sample8 = [&](size_t idx) -> int {  // idx-th sample of the row as 8 bits (16-bit: high byte)
             if (depth == 8) return cur[idx];
             if (depth == 16) return cur[idx * 2];
@@ -160,7 +179,13 @@ static bool decode_png(const std::vector<uint8_t>& d, std::vector<uint8_t>& img,
                 out[x] = rgb_to_gray(sample8((size_t)x * ch), sample8((size_t)x * ch + 1), sample8((size_t)x * ch + 2));
             }
         }
+        uint8_t* dst = &img[(size_t)(y0 + y * dy) * W + x0];
+        for (int x = 0; x < w; x++) dst[(size_t)x * dx] = out[x];
     }
+    pass_off += (rowbytes + 1) * (size_t)h;
+    }
+    w = W;
+    h = H;
     return true;
 }
 
