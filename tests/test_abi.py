@@ -78,3 +78,44 @@ def test_product_does_not_reference_oracle():
             if fn.endswith((".py", ".hip", ".h", ".cpp", ".cc", ".js", "Makefile", ".gyp")):
                 txt = open(os.path.join(dp, fn), errors="ignore").read()
                 assert "oracle" not in txt.lower() or fn == "synth.py" and "CPU oracle" in txt, fn
+
+
+def test_header_is_plain_c_and_links(tmp_path):
+    """include/twflow.h is a C header (no C++-isms, no torch/HIP types): a C99 translation unit that uses the
+    entry points of a consumer compiles with -pedantic -Werror, links against libtwflow.so and runs the calls
+    that need no device."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    src = tmp_path / "consumer.c"
+    src.write_text(r"""
+#include <stdio.h>
+#include "twflow.h"
+int main(void)
+{
+    tw_params p;
+    tw_engine* e = 0;
+    tw_vector v[4];
+    int n = 0;
+    float sec = 0.f;
+    tw_default_params(&p);
+    printf("%d %d %s\n", p.winSize, tw_grid_capacity(1920, 1080, 10), tw_strerror(TW_E_DONT_MATCH_SIZE));
+    if (tw_device_count() > 0 && tw_engine_create(0, &p, 1, &e) == TW_OK) {
+        unsigned char a[64 * 64] = {0}, b[64 * 64] = {0};
+        tw_status s = tw_diff_u8(e, a, b, 64, 64, 64, 10, 5.0, v, 4, &n, &sec);
+        printf("diff %d %d\n", (int)s, n);
+        tw_engine_destroy(e);
+    }
+    return 0;
+}
+""")
+    exe = tmp_path / "consumer"
+    libdir = os.path.join(ROOT, "tidal-wave_amd")
+    r = subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                        str(src), "-o", str(exe), "-L", libdir, "-ltwflow", "-Wl,-rpath," + libdir],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.splitlines()[0] == "30 20736 Don't match image size"
