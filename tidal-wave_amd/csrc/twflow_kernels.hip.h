@@ -1070,8 +1070,8 @@ struct BlurArgs {
 //   * the horizontal results of all 5 planes stay in registers: 3 workgroup barriers instead of 7
 //   * solve / refresh phase handles two pixels per step (more gathers in flight per lane)
 // -----------------------------------------------------------------------------------------------------
-template <int MH, int COLS, int HALO, int TH, bool FUSED, int VILP = 2, int HILP = 2, int SUNROLL = 2>
-__global__ __launch_bounds__(COLS) void tw_blur_solve4(BlurArgs a)
+template <int MH, int COLS, int HALO, int TH, bool FUSED, int VILP = 2, int HILP = 2, int SUNROLL = 2, bool QPRE = true>
+__global__ __launch_bounds__(COLS) __attribute__((amdgpu_waves_per_eu(4, 8))) void tw_blur_solve4(BlurArgs a)
 {
     constexpr int TW = COLS - 2 * HALO;
     constexpr int NW = TH + 2 * MH;
@@ -1124,6 +1124,24 @@ __global__ __launch_bounds__(COLS) void tw_blur_solve4(BlurArgs a)
     constexpr int NITEM = TH * GROUPS;
     constexpr int ROUNDS = (NITEM + COLS - 1) / COLS;
     constexpr int WL = 4 + 2 * HALO;
+    constexpr int NPX = TH * TW / COLS;
+    // QPRE: the R0 coefficients of the lane's S-phase pixels do not depend on the flow — fetch them now, so that a
+    // third of the refresh's loads move under the horizontal arithmetic (+1 % pairs/s; 110 VGPRs, still 4 waves/SIMD)
+    float qpre[QPRE ? NPX : 1][5];
+    if constexpr (QPRE && FUSED) {
+        if (a.update) {
+            const float* __restrict__ R0p = a.R + (long long)(2 * z) * 5 * a.ps;
+#pragma unroll
+            for (int i = 0; i < NPX; i++) {
+                const int p = tid + i * COLS;
+                const int r = p / TW, cx = p - r * TW;
+                const int xc = clampi(x0 + cx, 0, a.w - 1), yc = min(y0 + r, a.h - 1);
+                const long long o = (long long)yc * a.ld + xc;
+#pragma unroll
+                for (int cc = 0; cc < 5; cc++) qpre[i][cc] = R0p[o + cc * a.ps];
+            }
+        }
+    }
     f32x4 res[ROUNDS][5];
 #pragma unroll
     for (int rd = 0; rd < ROUNDS; rd++) {
@@ -1172,8 +1190,10 @@ __global__ __launch_bounds__(COLS) void tw_blur_solve4(BlurArgs a)
     static_assert((TH * TW) % COLS == 0, "pixels per lane must be whole");
     // Every lane always computes (on a clamped, valid pixel); only the stores are predicated, so the loop body
     // has no control flow and the gathers of SUNROLL pixels are in flight together.
-#pragma unroll SUNROLL
-    for (int p = tid; p < TH * TW; p += COLS) {
+#pragma unroll
+    for (int i = 0; i < NPX; i++) {
+        if (i % SUNROLL == 0) __builtin_amdgcn_sched_barrier(0);  // SUNROLL pixels in flight
+        const int p = tid + i * COLS;
         const int r = p / TW, cx = p - r * TW;
         const int x = x0 + cx, y = y0 + r;
         const bool valid = x >= 0 && x < a.w && y < a.h;
@@ -1191,7 +1211,8 @@ __global__ __launch_bounds__(COLS) void tw_blur_solve4(BlurArgs a)
         if (FUSED) {
             if (a.update) {  // wave-uniform
                 float M[5];
-                update_matrices_px(R0, R1, a.ps, a.ld, a.w, a.h, xc, yc, fxv, fyv, M);
+                if constexpr (QPRE) update_matrices_core(qpre[i], R1, a.ps, a.ld, a.w, a.h, xc, yc, fxv, fyv, M);
+                else update_matrices_px(R0, R1, a.ps, a.ld, a.w, a.h, xc, yc, fxv, fyv, M);
                 if (valid) {
 #pragma unroll
                     for (int cc = 0; cc < 5; cc++) Mout[o + cc * a.ps] = M[cc];
