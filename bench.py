@@ -184,6 +184,25 @@ def main():
                 breakdown[twflow.KERNEL_NAMES[kc]] = {"us_per_pair": round(ms * 1e3 / args.batch, 2), "launches": n}
             eng.prof_select(-1, -2)
 
+    # secondary figure, outside the timed region and never `value`: the same batches with the engine option that
+    # evaluates the last level-0 iteration only at the span-grid points the scan reads (identical status / vectors,
+    # the dense flow field of the last iteration is not materialised)
+    fused_rate = None
+    if world == 1:
+        eng.set_option(twflow.OPT_SCAN_FUSED_FINAL, 1)
+        before = flagged[0]
+        step()
+        per_step = flagged[0] - before
+        torch.cuda.synchronize()
+        tf = time.perf_counter()
+        nf = max(2, args.steps // 2)
+        for _ in range(nf):
+            step()
+        torch.cuda.synchronize()
+        fused_rate = args.batch * nf / (time.perf_counter() - tf)
+        fused_same = (flagged[0] - before) == per_step * (nf + 1)
+        eng.set_option(twflow.OPT_SCAN_FUSED_FINAL, 0)
+
     if rank == 0:
         value = pairs_total / elapsed
         bytes_pair = eng.algorithmic_bytes_pair(W, H, SPAN)
@@ -256,6 +275,10 @@ def main():
                               "frac_of_measured_copy": round(bytes_pair * value / world / 1e9 / copy_gbs, 4)
                               if copy_gbs else None},
             "kernel_breakdown": breakdown,
+            "scan_fused_final": None if fused_rate is None else {
+                "pairs_per_s": round(fused_rate, 2), "note": "engine option TW_OPT_SCAN_FUSED_FINAL: last level-0 "
+                "iteration evaluated at the span-grid points only; same vectors; not the headline value",
+                "hits_per_step_constant": bool(fused_same)},
             "roofline": roof(twflow.K_BLUR_SOLVE),
             "roofline_polyexp": roof(twflow.K_POLYEXP),
             "flagged_vectors": flagged_total,

@@ -118,6 +118,15 @@ tw_status tw_dev_alloc(tw_engine* e, size_t bytes, void** dptr);
 tw_status tw_dev_free(tw_engine* e, void* dptr);
 tw_status tw_dev_upload(tw_engine* e, void* dptr, const void* host, size_t bytes);
 
+/* Engine options.
+ * TW_OPT_SCAN_FUSED_FINAL (default 0): tw_submit_* / tw_diff_u8 with span 10 and winSize 30/31 evaluate the last
+ *   window average + solve of level 0 only at the span-grid points the scan reads.  Status and vectors are
+ *   bit-identical; the dense flow field of that last iteration is simply never materialised (tw_flow_u8 always
+ *   computes the whole field).  Off by default because the reference's path — and bench.py's headline — produce
+ *   the full field. */
+enum { TW_OPT_SCAN_FUSED_FINAL = 1 };
+tw_status tw_set_option(tw_engine* e, int option, int value);
+
 /* Page-locked host memory.  Images handed to tw_submit_u8 from such memory (or from memory the caller
  * registered with hipHostRegister) are DMA-ed to the device straight from the caller's buffer on the engine's
  * copy stream — no staging copy — and must therefore stay unchanged until tw_wait() of the ticket returns.

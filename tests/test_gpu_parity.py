@@ -353,6 +353,44 @@ def test_two_engines_on_two_threads(twflow, oracle):
             assert got == want
 
 
+def test_scan_fused_final_iteration_option(twflow, oracle, golden):
+    """TW_OPT_SCAN_FUSED_FINAL: the last level-0 window average + solve only at the span-grid points.  Hits are
+    bit-identical to the oracle's (golden pair, ragged sizes, sizes with a partial last grid row / column,
+    thresholds that flag every point), in batches, and other spans / window sizes fall back to the full path."""
+    import synth
+    rng = np.random.default_rng(77)
+    cases = []
+    g = golden["revision2_capture2"]
+    cases.append((g["expect_img"], g["target_img"]))
+    for (h, w) in [(117, 180), (279, 280), (480, 640), (33, 47), (10, 10), (11, 221), (219, 9), (231, 441), (1080, 1920)]:
+        if (h, w) == (1080, 1920):
+            cases.append(synth.make_pair(2, h, w))
+        else:
+            a = rand_img(rng, h, w)
+            cases.append((a, np.roll(a, (1, -3), axis=(0, 1))))
+    with twflow.Engine(0, twflow.default_params(), slots=4) as e:
+        e.set_option(twflow.OPT_SCAN_FUSED_FINAL, 1)
+        for a, b in cases:
+            wx, wy = oracle.farneback(a, b)
+            for thr in (5.0, 0.0):
+                assert e.diff(a, b, 10, thr)["vector"] == oracle.span_scan(wx, wy, 10, thr), (a.shape, thr)
+            assert e.diff(a, b, 7, 1.0)["vector"] == oracle.span_scan(wx, wy, 7, 1.0)   # other span: full path
+            gx, gy, _ = e.calculate_internal(a, b)                                         # dense flow: full path
+            assert_same(gx, wx, "flowx with the option on")
+        small = cases[1:5]
+        order = [small[0], small[0], small[1], small[1]]   # two batches of two
+        tk = [e.submit(a, b, 10, 1.0) for a, b in order]
+        got = [e.wait(t)["vector"] for t in tk]
+        for (a, b), v in zip(order, got):
+            wx, wy = oracle.farneback(a, b)
+            assert v == oracle.span_scan(wx, wy, 10, 1.0)
+    with twflow.Engine(0, twflow.default_params(winSize=13), slots=1) as e:
+        e.set_option(twflow.OPT_SCAN_FUSED_FINAL, 1)   # not the 31-tap window: full path
+        a, b = cases[1]
+        wx, wy = oracle.farneback(a, b, oracle.default_params(winSize=13))
+        assert e.diff(a, b, 10, 1.0)["vector"] == oracle.span_scan(wx, wy, 10, 1.0)
+
+
 def test_pinned_and_pageable_callers_agree(twflow, oracle):
     """tw_submit_u8 from page-locked caller memory (DMA straight from it, also with a row stride) and from
     ordinary memory (staged) — same hits as the oracle; batches overlap on the copy stream."""

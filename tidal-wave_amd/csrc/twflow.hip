@@ -298,6 +298,7 @@ struct tw_engine {
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int upd_ny = 2;        // TW_UPD_NY: pixels per lane of tw_update_matrices (1 or 2)
+    int scan_fused = 0;    // TW_OPT_SCAN_FUSED_FINAL
     int pyr_generic = 0;   // TW_PYR_GENERIC=1: always the generic pyramid kernel, 2: tw_pyr_level_lds for every level (A/B)
     int blur_variant = 4;  // 4: tw_blur_solve4 (default); 8: tw_blur_solve8 (packed f32) — TW_BLUR_VARIANT
     std::string err;
@@ -892,10 +893,30 @@ tw_status flush_ctx(tw_engine* e, Ctx& c)
                 launch_pyr(e, ls, pl, k, e->d_ptrs + 2 * j0, stride, I, 2 * nc);
                 if ((r = launch_polyexp(e, ls, L.w, L.h, L.ld, L.ps, I, R, 2 * nc, k))) return r;
                 launch_update(e, ls, pl, k, R, flow_cur, flow_prev, M0, nc);
-                for (int i = 0; i < it; i++)
+                // scan-fused final iteration (option TW_OPT_SCAN_FUSED_FINAL): nothing but the span grid of the last
+                // level-0 flow is read afterwards, so the last window average + solve runs at the grid points only
+                const bool grid_only = k == 0 && it > 0 && e->scan_fused && c.span == 10 && e->win_m == 15 && !e->box;
+                for (int i = 0; i < it; i++) {
+                    if (grid_only && i == it - 1) {
+                        BlurGridArgs g;
+                        g.Min = (i & 1) ? M1 : M0;
+                        g.w = L.w;
+                        g.h = L.h;
+                        g.ld = L.ld;
+                        g.ps = L.ps;
+                        g.gw = (L.w + c.span - 1) / c.span;
+                        g.gh = (L.h + c.span - 1) / c.span;
+                        g.gzs = (long long)g.gw * g.gh;
+                        g.g = e->d_grid + (size_t)j0 * g.gw * g.gh;
+                        g.c = e->wc;
+                        ProfScope pscope(e, ls, TW_K_BLUR_SOLVE, 0);
+                        hipLaunchKernelGGL((tw_blur_grid<15, 10, 2>), dim3((g.gw + 21) / 22, (g.gh + 1) / 2, nc), dim3(256), 0, ls, g);
+                        break;
+                    }
                     launch_blur(e, ls, L.w, L.h, L.ld, L.ps, (i & 1) ? M1 : M0, (i & 1) ? M0 : M1, flow_cur, R,
                                 i < it - 1, k, nc);
-                if (k == 0 && c.span > 0) {
+                }
+                if (k == 0 && c.span > 0 && !grid_only) {
                     // grid samples of this chunk -> dense per-pair buffer (the ordered scan runs once per batch)
                     GatherArgs g;
                     g.flow = flow_cur;
@@ -1349,6 +1370,15 @@ tw_status tw_dev_upload(tw_engine* e, void* dptr, const void* host, size_t bytes
     TW_HIP(e, hipSetDevice(e->device));
     TW_HIP(e, hipMemcpy(dptr, host, bytes, hipMemcpyHostToDevice));
     return TW_OK;
+}
+
+tw_status tw_set_option(tw_engine* e, int option, int value)
+{
+    if (!e) return TW_E_BAD_PARAMETER;
+    switch (option) {
+        case TW_OPT_SCAN_FUSED_FINAL: e->scan_fused = value ? 1 : 0; return TW_OK;
+        default: e->err = "unknown option"; return TW_E_BAD_PARAMETER;
+    }
 }
 
 tw_status tw_host_alloc(tw_engine* e, size_t bytes, void** hptr)

@@ -1528,6 +1528,95 @@ struct ScanRec {
     int x, y;
     float dx, dy;
 };
+// -----------------------------------------------------------------------------------------------------
+// tw_blur_grid<MH,SPAN,GR> : the LAST window average + solve of level 0 when nothing but the span grid is read
+//   afterwards (tw_submit / tw_diff with the scan-fused option): evaluated only at the grid points
+//   (x, y multiples of SPAN) and written straight into the dense grid buffer the ordered scan reads.
+//   Same arithmetic and order as tw_blur_solve4 for every value it produces: vertical centre-out sums over
+//   replicate-clamped rows, horizontal centre-out sums, 2x2 solve in double.
+//   Workgroup: 256 columns (22 grid columns + 15-column halos) x GR grid rows; one (GR-1)*SPAN + 2*MH + 1 row
+//   register window per column and plane.
+// -----------------------------------------------------------------------------------------------------
+struct BlurGridArgs {
+    const float* Min;  // pair z: 5 planes at Min + z*5*ps
+    float2* g;         // pair z: gw*gh points at g + z*gzs
+    int w, h, ld;
+    long long ps, gzs;
+    int gw, gh;
+    WinCoef c;
+};
+
+template <int MH, int SPAN, int GR>
+__global__ __launch_bounds__(256) void tw_blur_grid(BlurGridArgs a)
+{
+    constexpr int COLS = 256, XL = 16;       // the tile's first loaded column is XL left of its first grid column
+    constexpr int NGC = (COLS - XL - MH) / SPAN;  // grid columns per tile (the last one needs MH columns to its right)
+    constexpr int NW = (GR - 1) * SPAN + 2 * MH + 1;
+    static_assert(XL >= MH && 5 * GR * NGC <= COLS, "tile shape");
+    __shared__ float sm[5][GR][COLS];
+    __shared__ float res[5][GR][NGC];
+    const int tid = threadIdx.x;
+    const int bx = blockIdx.x, by = blockIdx.y, z = blockIdx.z;
+    const int x0 = bx * NGC * SPAN, gy0 = by * GR;
+    const WinCoef& c = a.c;
+    const float* __restrict__ Min = a.Min + (long long)z * 5 * a.ps;
+    {
+        const unsigned xb = (unsigned)clampi(x0 - XL + tid, 0, a.w - 1) * 4u;
+        unsigned ro[NW];
+#pragma unroll
+        for (int i = 0; i < NW; i++) ro[i] = (unsigned)clampi(gy0 * SPAN - MH + i, 0, a.h - 1) * ((unsigned)a.ld * 4u);
+        float wa[NW], wb[NW];
+        {
+            const __amdgpu_buffer_rsrc_t rs = make_rsrc(Min);
+#pragma unroll
+            for (int i = 0; i < NW; i++) wa[i] = bload(rs, xb, ro[i]);
+        }
+#pragma unroll
+        for (int ch = 0; ch < 5; ch++) {
+            float* cur = (ch & 1) ? wb : wa;
+            float* nxt = (ch & 1) ? wa : wb;
+            if (ch < 4) {
+                const __amdgpu_buffer_rsrc_t rs = make_rsrc(Min + (long long)(ch + 1) * a.ps);
+#pragma unroll
+                for (int i = 0; i < NW; i++) nxt[i] = bload(rs, xb, ro[i]);
+            }
+#pragma unroll
+            for (int j = 0; j < GR; j++) {
+                const int cc = j * SPAN + MH;
+                float s0 = cur[cc] * c.k[0];
+#pragma unroll
+                for (int i = 1; i <= MH; i++) s0 += (cur[cc + i] + cur[cc - i]) * c.k[i];
+                sm[ch][j][tid] = s0;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < 5 * GR * NGC) {
+        const int ch = tid / (GR * NGC), rem = tid - ch * (GR * NGC);
+        const int j = rem / NGC, gc = rem - j * NGC;
+        const float* v = &sm[ch][j][XL + gc * SPAN];
+        float sum = v[0] * c.k[0];
+#pragma unroll
+        for (int i = 1; i <= MH; i++) sum += c.k[i] * (v[-i] + v[i]);
+        res[ch][j][gc] = sum;
+    }
+    __syncthreads();
+    if (tid < GR * NGC) {
+        const int j = tid / NGC, gc = tid - j * NGC;
+        const int gx = bx * NGC + gc, gy = gy0 + j;
+        if (gx < a.gw && gy < a.gh) {
+            const double g11 = res[0][j][gc], g12 = res[1][j][gc], g22 = res[2][j][gc], h1 = res[3][j][gc],
+                         h2 = res[4][j][gc];
+            const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
+            float2 o;
+            o.x = (float)((g11 * h2 - g12 * h1) * idet);
+            o.y = (float)((g22 * h1 - g12 * h2) * idet);
+            a.g[(long long)z * a.gzs + (long long)gy * a.gw + gx] = o;
+        }
+    }
+}
+
 struct GatherArgs {
     const float* flow;  // pair z: 2 planes at flow + z*fzs
     long long fzs, fps;

@@ -44,10 +44,12 @@ class TwError(RuntimeError):
 _lib = None
 
 # every symbol include/twflow.h declares
+OPT_SCAN_FUSED_FINAL = 1
+
 SYMBOLS = [
     "tw_default_params", "tw_device_count", "tw_engine_create", "tw_engine_destroy", "tw_strerror",
     "tw_last_error", "tw_flow_u8", "tw_diff_u8", "tw_submit_u8", "tw_submit_dev", "tw_flush", "tw_wait",
-    "tw_grid_capacity", "tw_dev_alloc", "tw_dev_free", "tw_dev_upload", "tw_host_alloc", "tw_host_free",
+    "tw_grid_capacity", "tw_dev_alloc", "tw_dev_free", "tw_dev_upload", "tw_host_alloc", "tw_host_free", "tw_set_option",
     "tw_prof_select", "tw_prof_read",
     "tw_algorithmic_bytes", "tw_algorithmic_bytes_pair", "tw_num_levels", "tw_level_chunk", "tw_bench_stage", "tw_stage_pyr_level",
     "tw_stage_polyexp", "tw_stage_update_matrices", "tw_stage_flow_upsample_update", "tw_stage_blur_solve",
@@ -90,6 +92,7 @@ def lib():
     L.tw_dev_upload.argtypes = [vp, vp, vp, C.c_size_t]
     L.tw_host_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
     L.tw_host_free.argtypes = [vp, vp]
+    L.tw_set_option.argtypes = [vp, C.c_int, C.c_int]
     L.tw_prof_select.argtypes = [vp, C.c_int, C.c_int]
     L.tw_prof_read.argtypes = [vp, C.c_int, C.POINTER(C.c_double), ip]
     L.tw_algorithmic_bytes.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int]
@@ -259,6 +262,9 @@ class Engine:
         self._devbufs.append(d)
         self._check(self._L.tw_dev_upload(self._h, d, arr.ctypes.data_as(C.c_void_p), arr.nbytes))
         return d
+
+    def set_option(self, option, value):
+        self._check(self._L.tw_set_option(self._h, option, int(value)))
 
     def host_array(self, shape):
         """uint8 array in page-locked memory (tw_host_alloc): submit() DMAs straight from it, without staging.
