@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="no per-kernel hipEvents in the timed region")
     ap.add_argument("--cpu-pairs", type=int, default=0, help="pairs in the CPU sample (0: one per thread)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the untimed extra steps (kernel breakdown, scan-fused figure): a profiler trace then "
+                         "holds only the warm-up and the timed launches")
     return ap.parse_args()
 
 
@@ -171,7 +174,7 @@ def main():
             ms, n = eng.prof_read(kc)
             prof[kc] = (ms, n)
         eng.prof_select(-1, -2)
-        if rank == 0:
+        if rank == 0 and not args.no_extras:
             # outside the timed region: one more step with every launch of every kernel class bracketed (all
             # levels) -> where the time of a pair goes
             classes = (twflow.K_PYR, twflow.K_POLYEXP, twflow.K_UPDATE_MATRICES, twflow.K_BLUR_SOLVE, twflow.K_SCAN)
@@ -188,7 +191,7 @@ def main():
     # evaluates the last level-0 iteration only at the span-grid points the scan reads (identical status / vectors,
     # the dense flow field of the last iteration is not materialised)
     fused_rate = None
-    if world == 1:
+    if world == 1 and not args.no_extras:
         eng.set_option(twflow.OPT_SCAN_FUSED_FINAL, 1)
         before = flagged[0]
         step()
