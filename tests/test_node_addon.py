@@ -315,3 +315,39 @@ jobs.forEach(function(j){t.calc(j[0],j[1]);});
         assert d["expect_image"] == pa and (d["height"], d["width"]) == a.shape
         assert d["status"] == ("SUSPICIOUS" if want else "OK")
         assert [(v["x"], v["y"], v["dx"], v["dy"]) for v in d["vector"]] == [tuple(v) for v in want]
+
+
+@needs_node
+@pytest.mark.gpu
+def test_size_reconcile_within_five_pixels(tmp_path):
+    """src/opticalflow.cpp:52-68: sizes that differ by at most 5 px are reconciled (the target is resized to the
+    expected image's size, dims of the response are the expected image's); more than 5 px is "Don't match image
+    size".  The 8-bit bilinear resize itself is parity-unpinned (no fixture of the reference exercises it)."""
+    Image = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(3)
+    yy, xx = np.mgrid[0:90, 0:120]
+    a = ((np.sin(xx / 7.0) + np.cos(yy / 5.0)) * 60 + 128).astype(np.uint8)
+    pa = tmp_path / "e.png"
+    Image.fromarray(a).save(pa)
+    out = []
+    for k, (dh, dw) in enumerate([(0, 0), (3, -2), (-5, 5), (6, 0), (0, -6)]):
+        b = np.asarray(Image.fromarray(a).resize((120 + dw, 90 + dh), Image.BILINEAR))
+        pb = tmp_path / ("t%d.png" % k)
+        Image.fromarray(b).save(pb)
+        out.append(str(pb))
+    r = node("""
+var T=require('./index'); var t=new T.TidalWave({}); var res=[]; var n=0; var targets=process.argv.slice(2);
+function done(){ if(++n===targets.length) t.dispose(); }
+t.on('data',function(d){res.push({t:d.target_image,h:d.height,w:d.width,s:d.status}); done();});
+t.on('error',function(e){res.push({e:e.reason}); done();});
+t.on('finish',function(){console.log(JSON.stringify(res));});
+targets.forEach(function(p){t.calc(process.argv[1],p);});
+""", str(pa), *out, timeout=120)
+    assert r.returncode == 0, r.stderr[-400:]
+    res = json.loads(r.stdout.strip().splitlines()[-1])
+    data = [x for x in res if "t" in x]
+    errs = [x for x in res if "e" in x]
+    assert len(data) == 3 and all((d["h"], d["w"]) == (90, 120) for d in data)
+    assert sorted(e["e"] for e in errs) == ["Don't match image size"] * 2
+    same = [d for d in data if d["t"] == out[0]][0]
+    assert same["s"] == "OK"
