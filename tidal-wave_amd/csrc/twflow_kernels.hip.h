@@ -1063,12 +1063,15 @@ struct BlurArgs {
 };
 
 // -----------------------------------------------------------------------------------------------------
-// tw_blur_solve4<MH,COLS,HALO,TH,FUSED> : v3 with the stalls taken out.
-//   * the TH+2*MH clamped row offsets are computed once (SGPRs); the plane is selected by rebasing the buffer
-//     resource, so the vertical phase issues no address arithmetic at all
-//   * the next plane's register window is loaded while the current plane is being blurred (two windows)
-//   * the horizontal results of all 5 planes stay in registers: 3 workgroup barriers instead of 7
-//   * solve / refresh phase handles two pixels per step (more gathers in flight per lane)
+// tw_blur_solve4<MH,COLS,HALO,TH,FUSED> : K7, the window average of the 5 M planes + 2x2 solve (+ the fused
+//   FarnebackUpdateMatrices refresh for the next iteration).  A workgroup owns a (COLS-2*HALO) x TH tile.
+//   V : one column per lane; the TH+2*MH clamped row offsets are computed once (SGPRs) and the plane is selected
+//       by rebasing the buffer resource, so the vertical phase issues no address arithmetic at all; the next
+//       plane's register window is loaded while the current plane is being blurred (two windows)
+//   H : 4 pixels per item from LDS windows; the results of all 5 planes stay in registers (3 workgroup barriers),
+//       then go back to the tile interiors
+//   S : lane-consecutive pixels: solve in double, store the flow, refresh M (R0 fetched before H, two R1
+//       gathers in flight per lane)
 // -----------------------------------------------------------------------------------------------------
 template <int MH, int COLS, int HALO, int TH, bool FUSED, int VILP = 2, int HILP = 2, int SUNROLL = 2, bool QPRE = true>
 __global__ __launch_bounds__(COLS) __attribute__((amdgpu_waves_per_eu(4, 8))) void tw_blur_solve4(BlurArgs a)
@@ -1224,7 +1227,7 @@ __global__ __launch_bounds__(COLS) __attribute__((amdgpu_waves_per_eu(4, 8))) vo
 
 // -----------------------------------------------------------------------------------------------------
 // tw_blur_solve8<MH,COLS,HALO,TH,FUSED,PREFETCH> : v4's tiling and occupancy (COLS threads, 40 KB LDS, 4
-//   workgroups = 16 waves per CU) with packed f32 arithmetic (see v6 for why):
+//   workgroups = 16 waves per CU) with packed f32 arithmetic (DESIGN.md §5 has the measurements):
 //     V : one column per lane; output rows are produced in PAIRS (r, r+1): the window is held as even-aligned
 //         pairs {w[2j], w[2j+1]} plus a copy shifted by one row {w[2j+1], w[2j+2]}, so every tap of a row pair
 //         is one aligned register pair;  {s_r, s_r+1} += ({w[a], w[a+1]} + {w[b], w[b+1]}) * k
