@@ -114,6 +114,11 @@ def main():
         else:
             dist.init_process_group(backend=backend)
 
+    if not os.path.exists(os.path.join(ROOT, "tidal-wave_amd", "libtwflow.so")) and local_rank == 0:
+        import __graft_entry__  # fresh checkout: the binaries are git-ignored (building is not a fallback)
+        __graft_entry__.build()
+    if dist is not None:
+        dist.barrier()
     import synth
     import twflow
 

@@ -14,6 +14,12 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # a fresh checkout has no binaries (they are git-ignored): build them once, exactly as __graft_entry__.build()
+    # does (hipcc for the product library, gcc for the oracle, g++ for the node addon).  Building is not a fallback:
+    # a failing build fails the run.
+    if not os.path.exists(os.path.join(ROOT, "tidal-wave_amd", "libtwflow.so")):
+        import __graft_entry__
+        __graft_entry__.build()
 
 
 @pytest.fixture(scope="session")
