@@ -778,7 +778,8 @@ void launch_blur(tw_engine* e, hipStream_t st, int w, int h, int ld, long long p
         else hipLaunchKernelGGL((tw_blur_solve4<15, 128, 16, 8, true>), dim3((w + a.xsh + 95) / 96, gy, npairs), dim3(128), 0, st, a);
     } else if (e->win_m == 25) {
         // winSize 50/51 (BASELINE config 5): packed-f32 structure, single 58-row register window
-        if (wide) hipLaunchKernelGGL((tw_blur_solve8<25, 256, 32, 8, true, false>), dim3((w + 191) / 192, gy, npairs), dim3(256), 0, st, a);
+        if (wide && e->blur_variant != 8) hipLaunchKernelGGL((tw_blur_solve4<25, 256, 32, 8, true, 2, 2, 2, false, false>), dim3((w + 191) / 192, gy, npairs), dim3(256), 0, st, a);
+        else if (wide) hipLaunchKernelGGL((tw_blur_solve8<25, 256, 32, 8, true, false>), dim3((w + 191) / 192, gy, npairs), dim3(256), 0, st, a);
         else hipLaunchKernelGGL((tw_blur_solve8<25, 128, 32, 8, true, false>), dim3((w + 63) / 64, gy, npairs), dim3(128), 0, st, a);
     } else {
         // any other window size: generic kernel (same arithmetic, runtime loops)

@@ -1073,7 +1073,7 @@ struct BlurArgs {
 //   S : lane-consecutive pixels: solve in double, store the flow, refresh M (R0 fetched before H, two R1
 //       gathers in flight per lane)
 // -----------------------------------------------------------------------------------------------------
-template <int MH, int COLS, int HALO, int TH, bool FUSED, int VILP = 2, int HILP = 2, int SUNROLL = 2, bool QPRE = true>
+template <int MH, int COLS, int HALO, int TH, bool FUSED, int VILP = 2, int HILP = 2, int SUNROLL = 2, bool QPRE = true, bool VPRE = true>
 __global__ __launch_bounds__(COLS) __attribute__((amdgpu_waves_per_eu(4, 8))) void tw_blur_solve4(BlurArgs a)
 {
     constexpr int TW = COLS - 2 * HALO;
@@ -1095,7 +1095,7 @@ __global__ __launch_bounds__(COLS) __attribute__((amdgpu_waves_per_eu(4, 8))) vo
         unsigned ro[NW];  // wave-uniform byte offsets of the clamped rows
 #pragma unroll
         for (int i = 0; i < NW; i++) ro[i] = (unsigned)clampi(y0 - MH + i, 0, a.h - 1) * ((unsigned)a.ld * 4u);
-        float wa[NW], wb[NW];
+        float wa[NW], wb[VPRE ? NW : 1];
         {
             const __amdgpu_buffer_rsrc_t rs = make_rsrc(Min);
 #pragma unroll
@@ -1103,12 +1103,19 @@ __global__ __launch_bounds__(COLS) __attribute__((amdgpu_waves_per_eu(4, 8))) vo
         }
 #pragma unroll
         for (int ch = 0; ch < 5; ch++) {
-            float* cur = (ch & 1) ? wb : wa;
-            float* nxt = (ch & 1) ? wa : wb;
-            if (ch < 4) {
+            // VPRE: two windows, the next plane loads while this one is blurred; otherwise one window (wide
+            // kernels: 2*MH+TH rows would not fit twice) and the other workgroups of the CU cover the load
+            float* cur = (VPRE && (ch & 1)) ? wb : wa;
+            float* nxt = (VPRE && (ch & 1)) ? wa : wb;
+            if (VPRE && ch < 4) {
                 const __amdgpu_buffer_rsrc_t rs = make_rsrc(Min + (long long)(ch + 1) * a.ps);
 #pragma unroll
                 for (int i = 0; i < NW; i++) nxt[i] = bload(rs, xb, ro[i]);
+            }
+            if (!VPRE && ch > 0) {
+                const __amdgpu_buffer_rsrc_t rs = make_rsrc(Min + (long long)ch * a.ps);
+#pragma unroll
+                for (int i = 0; i < NW; i++) wa[i] = bload(rs, xb, ro[i]);
             }
 #pragma unroll
             for (int r = 0; r < TH; r++) {
