@@ -249,7 +249,8 @@ def test_many_hits_survive_later_batches(twflow, oracle):
 
 @pytest.mark.parametrize("kw", [dict(polyN=5, polySigma=1.1), dict(winSize=50, pyrIterations=2),
                                 dict(winSize=13, pyrIterations=1), dict(pyrLevels=0), dict(pyrLevels=1, pyrIterations=4),
-                                dict(pyrScale=0.8, pyrLevels=3), dict(pyrScale=0.6, pyrLevels=2, polyN=3)])
+                                dict(pyrScale=0.8, pyrLevels=3), dict(pyrScale=0.6, pyrLevels=2, polyN=3),
+                                dict(pyrIterations=0)])
 def test_non_default_parameters(twflow, oracle, kw):
     rng = np.random.default_rng(11)
     a = rand_img(rng, 150, 210)

@@ -802,6 +802,7 @@ void launch_update(tw_engine* e, hipStream_t st, const Plan* pl, int k, const fl
     a.ld = L.ld;
     a.ps = L.ps;
     a.fps = L.ps;
+    a.store_flow = e->p.pyrIterations == 0 ? 1 : 0;
     ProfScope pscope(e, st, TW_K_UPDATE_MATRICES, k);
     if (k < pl->levels) {
         const LevelPlan& P = pl->lv[k + 1];
@@ -1772,6 +1773,7 @@ tw_status tw_stage_flow_upsample_update(tw_engine* e, const float* R0_5, const f
     a.beta = d_be;
     a.xmax = u.xmax;
     a.scale = (float)(1. / e->p.pyrScale);
+    a.store_flow = 1;
     hipStream_t st = e->stream;
     launch_upd_kernel<true>(e, st, w, h, 1, a);
     TW_HIP(e, hipGetLastError());

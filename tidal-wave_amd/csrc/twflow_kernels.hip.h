@@ -943,7 +943,9 @@ struct UpdArgs {
     const float* beta;
     int xmax;
     float scale;  // (float)(1/pyr_scale)
-    int zero_flow;  // coarsest level: flow = 0 (written)
+    int zero_flow;  // coarsest level: flow = 0
+    int store_flow; // write the level's initial flow (only needed when no iteration follows: the first
+                    // blur+solve overwrites every flow value without reading it)
 };
 
 template <bool UPSAMPLE, int NY>
@@ -1024,7 +1026,7 @@ __global__ __launch_bounds__(256) void tw_update_matrices(UpdArgs a)
 #pragma unroll
     for (int j = 0; j < NY; j++) {
         if (yb + 4 * j < a.h) {
-            if (UPSAMPLE || a.zero_flow) {
+            if ((UPSAMPLE || a.zero_flow) && a.store_flow) {
                 flow[o[j]] = dx[j];
                 flow[o[j] + a.fps] = dy[j];
             }
