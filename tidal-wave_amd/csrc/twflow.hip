@@ -719,6 +719,7 @@ void launch_blur(tw_engine* e, hipStream_t st, int w, int h, int ld, long long p
     a.fps = ps;
     a.update = update;
     a.xsh = 0;
+    a.store_flow = level < 0 ? 1 : 0;  // level -1: the per-stage test entry point, which returns the flow as well
     a.m = e->win_m;
     a.c = e->wc;
     const int gy = (h + BS_TH - 1) / BS_TH;

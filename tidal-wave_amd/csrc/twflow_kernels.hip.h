@@ -1060,6 +1060,8 @@ struct BlurArgs {
     long long ps, fps;
     int update;  // refresh M (i < iterations-1)
     int xsh;     // tw_blur_solve4: the tile grid starts this many pixels left of the image
+    int store_flow;  // 1: store the flow of a refreshing launch too (nothing reads it: the refresh uses the value in
+                     // registers and the next launch overwrites it; the engine stores only the last iteration's)
     int m;       // runtime m for the generic kernel
     WinCoef c;
 };
@@ -1216,7 +1218,7 @@ __global__ __launch_bounds__(COLS) __attribute__((amdgpu_waves_per_eu(4, 8))) vo
         const float fxv = (float)((g11 * h2 - g12 * h1) * idet);
         const float fyv = (float)((g22 * h1 - g12 * h2) * idet);
         const long long o = (long long)yc * a.ld + xc;
-        if (valid) {
+        if (valid && (!a.update || a.store_flow)) {
             flow[o] = fxv;
             flow[o + a.fps] = fyv;
         }
@@ -1395,8 +1397,10 @@ __global__ __launch_bounds__(COLS) void tw_blur_solve8(BlurArgs a)
             const float fxv = (float)((g11 * h2 - g12 * h1) * idet);
             const float fyv = (float)((g22 * h1 - g12 * h2) * idet);
             const long long o = (long long)y * a.ld + x;
-            flow[o] = fxv;
-            flow[o + a.fps] = fyv;
+            if (!a.update || a.store_flow) {
+                flow[o] = fxv;
+                flow[o + a.fps] = fyv;
+            }
             if (FUSED) {
                 if (a.update) {
                     float M[5];
@@ -1454,8 +1458,10 @@ __global__ __launch_bounds__(256) void tw_blur_solve_generic(BlurArgs a)
         const float fxv = (float)((g11 * h2 - g12 * h1) * idet);
         const float fyv = (float)((g22 * h1 - g12 * h2) * idet);
         const long long o = (long long)y * a.ld + x;
-        flow[o] = fxv;
-        flow[o + a.fps] = fyv;
+        if (!a.update || a.store_flow) {
+            flow[o] = fxv;
+            flow[o + a.fps] = fyv;
+        }
         if (a.update) {
             float M[5];
             update_matrices_px(R0, R1, a.ps, a.ld, a.w, a.h, x, y, fxv, fyv, M);
