@@ -3,7 +3,9 @@
 
 Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 it is launched through
 torch.distributed.run, one rank per GPU.  One "step" = one pass of the hot path over one batch of
-BATCH synthetic 1920x1080 pairs that are already resident in HBM when the timed region starts (BASELINE.json
+BATCH synthetic 1920x1080 pairs that are already resident in HBM when the timed region starts; inside the timed
+region batch s+1 is submitted before the results of batch s are collected (a service's steady state: the engine
+keeps up to three batches outstanding), all K batches complete inside the region (BASELINE.json
 config "batch of 1080p pairs, 1xMI355X"; the single-pair latency of configs[1] is reported beside it).
 Pairs shard embarrassingly across ranks (weak scaling: every rank processes its own batch); there is no
 data-path collective — torch.distributed (RCCL) is used only for the barrier and the max-over-ranks of
@@ -138,15 +140,31 @@ def main():
 
     flagged = [0]
 
-    def step():
-        # submit the whole batch (the engine launches every `slots` pairs, level-major), then collect
+    def submit_step():
+        # submit the whole batch (the engine launches every `slots` pairs, level-major)
         tickets = []
         for j in range(args.batch):
             da, db = dev_pairs[j % len(dev_pairs)]
             tickets.append(eng.submit_dev(da, db, W, H, W, SPAN, THRESHOLD))
+        return tickets
+
+    def collect(tickets):
         for t in tickets:
             n, _ = eng.wait_count(t)
             flagged[0] += n
+
+    def step():
+        collect(submit_step())
+
+    def run_steps(k):
+        # steady state of a service: the next batch is handed over while the previous one computes (the engine keeps
+        # up to three batches outstanding), so the GPU does not idle during the host's submit calls
+        prev = submit_step()
+        for _ in range(k - 1):
+            cur = submit_step()
+            collect(prev)
+            prev = cur
+        collect(prev)
 
     # single-pair latency (configs[1]) and a result check before timing
     res0 = eng.diff(host_pairs[0][0], host_pairs[0][1], SPAN, THRESHOLD)
@@ -163,8 +181,7 @@ def main():
         eng.prof_select(twflow.K_POLYEXP, 0)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    run_steps(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
     import shard
@@ -204,8 +221,7 @@ def main():
         torch.cuda.synchronize()
         tf = time.perf_counter()
         nf = max(2, args.steps // 2)
-        for _ in range(nf):
-            step()
+        run_steps(nf)
         torch.cuda.synchronize()
         fused_rate = args.batch * nf / (time.perf_counter() - tf)
         fused_same = (flagged[0] - before) == per_step * (nf + 1)
