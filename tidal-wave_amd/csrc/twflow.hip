@@ -719,6 +719,7 @@ void launch_blur(tw_engine* e, hipStream_t st, int w, int h, int ld, long long p
     a.fps = ps;
     a.update = update;
     a.xsh = 0;
+    a.rot = 0;
     a.store_flow = level < 0 ? 1 : 0;  // level -1: the per-stage test entry point, which returns the flow as well
     a.m = e->win_m;
     a.c = e->wc;
@@ -774,6 +775,7 @@ void launch_blur(tw_engine* e, hipStream_t st, int w, int h, int ld, long long p
         // shift the tile grid 16 px left when that costs no extra tile column (see the kernel)
         const int tw = wide ? 224 : 96;
         a.xsh = ((w + 16 + tw - 1) / tw == (w + tw - 1) / tw) ? 16 : 0;
+        a.rot = a.xsh;
         if (wide && e->blur_variant == 6) hipLaunchKernelGGL((tw_blur_solve4<15, 256, 16, 8, true, 2, 2, 2, false>), dim3((w + a.xsh + 223) / 224, gy, npairs), dim3(256), 0, st, a);
         else if (wide) hipLaunchKernelGGL((tw_blur_solve4<15, 256, 16, 8, true>), dim3((w + a.xsh + 223) / 224, gy, npairs), dim3(256), 0, st, a);
         else hipLaunchKernelGGL((tw_blur_solve4<15, 128, 16, 8, true>), dim3((w + a.xsh + 95) / 96, gy, npairs), dim3(128), 0, st, a);

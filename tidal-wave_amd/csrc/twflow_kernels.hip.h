@@ -1060,6 +1060,7 @@ struct BlurArgs {
     long long ps, fps;
     int update;  // refresh M (i < iterations-1)
     int xsh;     // tw_blur_solve4: the tile grid starts this many pixels left of the image
+    int rot;     // tw_blur_solve4: the S phase's pixel order is rotated by this many pixels within a row (= xsh)
     int store_flow;  // 1: store the flow of a refreshing launch too (nothing reads it: the refresh uses the value in
                      // registers and the next launch overwrites it; the engine stores only the last iteration's)
     int m;       // runtime m for the generic kernel
@@ -1148,7 +1149,7 @@ __global__ __launch_bounds__(COLS) __attribute__((amdgpu_waves_per_eu(4, 8))) vo
 #pragma unroll
             for (int i = 0; i < NPX; i++) {
                 const int p = tid + i * COLS;
-                const int r = p / TW, cx = p - r * TW;
+                const int r = p / TW, c0 = p - r * TW + a.rot, cx = c0 >= TW ? c0 - TW : c0;
                 const int xc = clampi(x0 + cx, 0, a.w - 1), yc = min(y0 + r, a.h - 1);
                 const long long o = (long long)yc * a.ld + xc;
 #pragma unroll
@@ -1208,7 +1209,9 @@ __global__ __launch_bounds__(COLS) __attribute__((amdgpu_waves_per_eu(4, 8))) vo
     for (int i = 0; i < NPX; i++) {
         if (i % SUNROLL == 0) __builtin_amdgcn_sched_barrier(0);  // SUNROLL pixels in flight
         const int p = tid + i * COLS;
-        const int r = p / TW, cx = p - r * TW;
+        // rotated by xsh within the row: the 64 consecutive pixels of a wave then start on a 128-byte boundary,
+        // like the vertical phase's row segments (the tile itself starts xsh pixels left of one)
+        const int r = p / TW, c0 = p - r * TW + a.rot, cx = c0 >= TW ? c0 - TW : c0;
         const int x = x0 + cx, y = y0 + r;
         const bool valid = x >= 0 && x < a.w && y < a.h;
         const int xc = clampi(x, 0, a.w - 1), yc = min(y, a.h - 1);
