@@ -1573,7 +1573,7 @@ __global__ __launch_bounds__(256) void tw_blur_grid(BlurGridArgs a)
     constexpr int COLS = 256, XL = 16;       // the tile's first loaded column is XL left of its first grid column
     constexpr int NGC = (COLS - XL - MH) / SPAN;  // grid columns per tile (the last one needs MH columns to its right)
     constexpr int NW = (GR - 1) * SPAN + 2 * MH + 1;
-    static_assert(XL >= MH && 5 * GR * NGC <= COLS, "tile shape");
+    static_assert(XL >= MH && GR * NGC <= COLS, "tile shape");
     __shared__ float sm[5][GR][COLS];
     __shared__ float res[5][GR][NGC];
     const int tid = threadIdx.x;
@@ -1586,7 +1586,8 @@ __global__ __launch_bounds__(256) void tw_blur_grid(BlurGridArgs a)
         unsigned ro[NW];
 #pragma unroll
         for (int i = 0; i < NW; i++) ro[i] = (unsigned)clampi(gy0 * SPAN - MH + i, 0, a.h - 1) * ((unsigned)a.ld * 4u);
-        float wa[NW], wb[NW];
+        constexpr bool PRE = NW <= 48;  // two windows only while they fit the register budget
+        float wa[NW], wb[PRE ? NW : 1];
         {
             const __amdgpu_buffer_rsrc_t rs = make_rsrc(Min);
 #pragma unroll
@@ -1594,12 +1595,17 @@ __global__ __launch_bounds__(256) void tw_blur_grid(BlurGridArgs a)
         }
 #pragma unroll
         for (int ch = 0; ch < 5; ch++) {
-            float* cur = (ch & 1) ? wb : wa;
-            float* nxt = (ch & 1) ? wa : wb;
-            if (ch < 4) {
+            float* cur = (PRE && (ch & 1)) ? wb : wa;
+            float* nxt = (PRE && (ch & 1)) ? wa : wb;
+            if (PRE && ch < 4) {
                 const __amdgpu_buffer_rsrc_t rs = make_rsrc(Min + (long long)(ch + 1) * a.ps);
 #pragma unroll
                 for (int i = 0; i < NW; i++) nxt[i] = bload(rs, xb, ro[i]);
+            }
+            if (!PRE && ch > 0) {
+                const __amdgpu_buffer_rsrc_t rs = make_rsrc(Min + (long long)ch * a.ps);
+#pragma unroll
+                for (int i = 0; i < NW; i++) wa[i] = bload(rs, xb, ro[i]);
             }
 #pragma unroll
             for (int j = 0; j < GR; j++) {
@@ -1613,8 +1619,8 @@ __global__ __launch_bounds__(256) void tw_blur_grid(BlurGridArgs a)
         }
     }
     __syncthreads();
-    if (tid < 5 * GR * NGC) {
-        const int ch = tid / (GR * NGC), rem = tid - ch * (GR * NGC);
+    for (int it = tid; it < 5 * GR * NGC; it += COLS) {
+        const int ch = it / (GR * NGC), rem = it - ch * (GR * NGC);
         const int j = rem / NGC, gc = rem - j * NGC;
         const float* v = &sm[ch][j][XL + gc * SPAN];
         float sum = v[0] * c.k[0];
