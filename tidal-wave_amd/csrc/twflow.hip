@@ -776,7 +776,9 @@ void launch_blur(tw_engine* e, hipStream_t st, int w, int h, int ld, long long p
         const int tw = wide ? 224 : 96;
         a.xsh = ((w + 16 + tw - 1) / tw == (w + tw - 1) / tw) ? 16 : 0;
         a.rot = a.xsh;
-        if (wide && e->blur_variant == 6) hipLaunchKernelGGL((tw_blur_solve4<15, 256, 16, 8, true, 2, 2, 2, false>), dim3((w + a.xsh + 223) / 224, gy, npairs), dim3(256), 0, st, a);
+        if (wide && e->blur_variant == 2) hipLaunchKernelGGL((tw_blur_solve4y<15, 256, 16, 8, 2>), dim3((w + a.xsh + 223) / 224, (h + 15) / 16, npairs), dim3(256), 0, st, a);
+        else if (wide && e->blur_variant == 7) hipLaunchKernelGGL((tw_blur_solve4<15, 256, 16, 8, true, 2, 2, 2, true, false>), dim3((w + a.xsh + 223) / 224, gy, npairs), dim3(256), 0, st, a);
+        else if (wide && e->blur_variant == 6) hipLaunchKernelGGL((tw_blur_solve4<15, 256, 16, 8, true, 2, 2, 2, false>), dim3((w + a.xsh + 223) / 224, gy, npairs), dim3(256), 0, st, a);
         else if (wide) hipLaunchKernelGGL((tw_blur_solve4<15, 256, 16, 8, true>), dim3((w + a.xsh + 223) / 224, gy, npairs), dim3(256), 0, st, a);
         else hipLaunchKernelGGL((tw_blur_solve4<15, 128, 16, 8, true>), dim3((w + a.xsh + 95) / 96, gy, npairs), dim3(128), 0, st, a);
     } else if (e->win_m == 25) {

@@ -11,6 +11,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace twk {
 
@@ -1236,6 +1237,176 @@ __global__ __launch_bounds__(COLS) __attribute__((amdgpu_waves_per_eu(4, 8))) vo
                 }
             }
         }
+    }
+}
+
+// -----------------------------------------------------------------------------------------------------
+// tw_blur_solve4y<MH,COLS,HALO,TH,NSUB> : tw_blur_solve4 with NSUB vertically adjacent TH-row sub-tiles per workgroup.
+//   The vertical pass runs once over a TH*NSUB + 2*MH row register window (the window rows of adjacent sub-tiles
+//   overlap in all but TH rows, so the L2 -> L1 window traffic per output row drops from (TH+2MH)/TH to
+//   (NSUB*TH+2MH)/(NSUB*TH)); the first sub-tile's results go to LDS, the others wait in registers until the
+//   LDS tile is free again.  Horizontal pass, solve and refresh are tw_blur_solve4's, once per sub-tile.
+//   Same values, same order.  One register window (no next-plane prefetch), R0 prefetched for the last sub-tile.
+// -----------------------------------------------------------------------------------------------------
+template <int MH, int COLS, int HALO, int TH, int NSUB, int VILP = 2, int HILP = 2, int SUNROLL = 2>
+__global__ __launch_bounds__(COLS) __attribute__((amdgpu_waves_per_eu(4, 8))) void tw_blur_solve4y(BlurArgs a)
+{
+    constexpr int TW = COLS - 2 * HALO;
+    constexpr int NR = TH * NSUB;
+    constexpr int NW = NR + 2 * MH;
+    __shared__ __attribute__((aligned(16))) float sm[5][TH][COLS];
+    const int tid = threadIdx.x;
+    int bx, by, z;
+    xcd_remap(bx, by, z);
+    const int x0 = bx * TW - a.xsh, y00 = by * NR;
+    const WinCoef& c = a.c;
+    const float* __restrict__ Min = a.Min + (long long)z * 5 * a.ps;
+    float* __restrict__ flow = a.flow + (long long)z * 2 * a.fps;
+    float* __restrict__ Mout = a.Mout + (long long)z * 5 * a.ps;
+    const float* __restrict__ R0 = a.R + (long long)(2 * z) * 5 * a.ps;
+    const float* __restrict__ R1 = R0 + 5 * a.ps;
+
+    // ---- V: all sub-tiles ----
+    float vlate[5][NR - TH];  // vertical results of the sub-tiles after the first
+    {
+        unsigned xb = (unsigned)clampi(x0 - HALO + tid, 0, a.w - 1) * 4u;
+        const unsigned pitch = (unsigned)a.ld * 4u;
+        float wa[NW];
+#pragma unroll
+        for (int ch = 0; ch < 5; ch++) {
+            const __amdgpu_buffer_rsrc_t rs = make_rsrc(Min + (long long)ch * a.ps);
+            // the NW clamped row offsets are recomputed per plane on the scalar unit (an opaque zero keeps the
+            // compiler from hoisting all NW of them into SGPRs for the whole kernel: 46 + the 16 coefficients + the
+            // arguments do not fit, and the overflow would land in VGPRs)
+            int zero;
+            asm volatile("s_mov_b32 %0, 0" : "=s"(zero));
+#pragma unroll
+            for (int i = 0; i < NW; i++)
+                wa[i] = bload(rs, xb, (unsigned)clampi(y00 - MH + i + zero, 0, a.h - 1) * pitch);
+#pragma unroll
+            for (int r = 0; r < NR; r++) {
+                float s0 = wa[r + MH] * c.k[0];
+#pragma unroll
+                for (int i = 1; i <= MH; i++) s0 += (wa[r + MH + i] + wa[r + MH - i]) * c.k[i];
+                if (r < TH) sm[ch][r][tid] = s0;
+                else {
+                    vlate[ch][r - TH] = s0;
+                    asm volatile("" : "+v"(vlate[ch][r - TH]));  // a scalar in a VGPR, not a lane of a wide vector value
+                }
+                if ((r & (VILP - 1)) == VILP - 1) __builtin_amdgcn_sched_barrier(0);
+                // the next plane's loads use xb: tying it to this plane's last result keeps them (and their 46
+                // registers) below this plane's arithmetic — one window at a time
+                if (r == NR - 1) asm volatile("" : "+v"(xb) : "v"(s0));
+            }
+        }
+    }
+
+    constexpr int GROUPS = TW / 4;
+    constexpr int NITEM = TH * GROUPS;
+    constexpr int ROUNDS = (NITEM + COLS - 1) / COLS;
+    constexpr int WL = 4 + 2 * HALO;
+    constexpr int NPX = TH * TW / COLS;
+    static_assert((TH * TW) % COLS == 0, "pixels per lane must be whole");
+    static_assert(NSUB == 2, "two sub-tiles");
+    auto subtile = [&](auto last_c, const int y0) __attribute__((always_inline)) {
+        constexpr bool last = decltype(last_c)::value;
+        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+        // the lane index is made opaque here: everything the H and S phases derive from it (LDS addresses, pixel
+        // coordinates, 64-bit global offsets of 7 pixels) would otherwise be hoisted above the vertical phase and
+        // sit in ~40 VGPRs while the register window and the late results need them
+        int t = tid;
+        asm volatile("" : "+v"(t));
+        float qpre[last ? NPX : 1][5];
+        if (last && a.update) {  // `last` is a compile-time constant here
+#pragma unroll
+            for (int i = 0; i < NPX; i++) {
+                const int p = t + i * COLS;
+                const int r = p / TW, c0 = p - r * TW + a.rot, cx = c0 >= TW ? c0 - TW : c0;
+                const int xc = clampi(x0 + cx, 0, a.w - 1), yc = min(y0 + r, a.h - 1);
+                const long long o = (long long)yc * a.ld + xc;
+#pragma unroll
+                for (int cc = 0; cc < 5; cc++) qpre[i][cc] = R0[o + cc * a.ps];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 res[ROUNDS][5];
+#pragma unroll
+        for (int rd = 0; rd < ROUNDS; rd++) {
+            const int it = t + rd * COLS;
+            if (it < NITEM) {
+                const int r = it / GROUPS, q = it - r * GROUPS;
+#pragma unroll
+                for (int ch = 0; ch < 5; ch++) {
+                    float v[WL];
+#pragma unroll
+                    for (int u = 0; u < WL / 4; u++) {
+                        const f32x4 A = *(const f32x4*)&sm[ch][r][4 * q + 4 * u];
+                        v[4 * u] = A[0];
+                        v[4 * u + 1] = A[1];
+                        v[4 * u + 2] = A[2];
+                        v[4 * u + 3] = A[3];
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const int li = HALO + j;
+                        float sum = v[li] * c.k[0];
+#pragma unroll
+                        for (int i = 1; i <= MH; i++) sum += c.k[i] * (v[li - i] + v[li + i]);
+                        res[rd][ch][j] = sum;
+                        if ((j & (HILP - 1)) == HILP - 1) __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int rd = 0; rd < ROUNDS; rd++) {
+            const int it = t + rd * COLS;
+            if (it < NITEM) {
+                const int r = it / GROUPS, q = it - r * GROUPS;
+#pragma unroll
+                for (int ch = 0; ch < 5; ch++) *(f32x4*)&sm[ch][r][HALO + 4 * q] = res[rd][ch];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NPX; i++) {
+            if (i % SUNROLL == 0) __builtin_amdgcn_sched_barrier(0);
+            const int p = t + i * COLS;
+            const int r = p / TW, c0 = p - r * TW + a.rot, cx = c0 >= TW ? c0 - TW : c0;
+            const int x = x0 + cx, y = y0 + r;
+            const bool valid = x >= 0 && x < a.w && y < a.h;
+            const int xc = clampi(x, 0, a.w - 1), yc = min(y, a.h - 1);
+            const double g11 = sm[0][r][HALO + cx], g12 = sm[1][r][HALO + cx], g22 = sm[2][r][HALO + cx],
+                         h1 = sm[3][r][HALO + cx], h2 = sm[4][r][HALO + cx];
+            const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
+            const float fxv = (float)((g11 * h2 - g12 * h1) * idet);
+            const float fyv = (float)((g22 * h1 - g12 * h2) * idet);
+            const long long o = (long long)yc * a.ld + xc;
+            if (valid && (!a.update || a.store_flow)) {
+                flow[o] = fxv;
+                flow[o + a.fps] = fyv;
+            }
+            if (a.update) {  // wave-uniform
+                float M[5];
+                if constexpr (last) update_matrices_core(qpre[i], R1, a.ps, a.ld, a.w, a.h, xc, yc, fxv, fyv, M);
+                else update_matrices_px(R0, R1, a.ps, a.ld, a.w, a.h, xc, yc, fxv, fyv, M);
+                if (valid) {
+#pragma unroll
+                    for (int cc = 0; cc < 5; cc++) Mout[o + cc * a.ps] = M[cc];
+                }
+            }
+        }
+    };
+    subtile(std::false_type{}, y00);
+    if (y00 + TH < a.h) {  // workgroup-uniform: otherwise the image ends inside the first sub-tile
+        __syncthreads();   // the first sub-tile's S phase has read the tile
+#pragma unroll
+        for (int ch = 0; ch < 5; ch++)
+#pragma unroll
+            for (int r = 0; r < TH; r++) sm[ch][r][tid] = vlate[ch][r];
+        subtile(std::true_type{}, y00 + TH);
     }
 }
 
