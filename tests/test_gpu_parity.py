@@ -392,6 +392,29 @@ def test_scan_fused_final_iteration_option(twflow, oracle, golden):
         assert e.diff(a, b, 10, 1.0)["vector"] == oracle.span_scan(wx, wy, 10, 1.0)
 
 
+def test_random_medium_shapes_default_and_wide_windows(twflow, oracle):
+    """Seeded random sizes between 100 and 700 px (every tile / halo / alignment path of the wide and narrow blur
+    kernels, the shifted tile grid, all pyramid kernels) with the default 31-tap window, the 51-tap one and a
+    generic one; whole flow field and hits, bit for bit."""
+    rng = np.random.default_rng(424242)
+    for k in range(12):
+        h, w = int(rng.integers(100, 700)), int(rng.integers(100, 700))
+        kw = [dict(), dict(winSize=50, pyrIterations=2), dict(winSize=21, pyrLevels=2)][k % 3]
+        a = rand_img(rng, h, w)
+        b = np.roll(a, (int(rng.integers(-3, 4)), int(rng.integers(-3, 4))), axis=(0, 1))
+        b[h // 3:h // 3 + 20, w // 4:w // 4 + 30] = 255 - b[h // 3:h // 3 + 20, w // 4:w // 4 + 30]
+        wx, wy = oracle.farneback(a, b, oracle.default_params(**kw))
+        with twflow.Engine(0, twflow.default_params(**kw), slots=2) as e:
+            gx, gy, _ = e.calculate_internal(a, b)
+            r = e.diff(a, b, 10, 2.0)
+            e.set_option(twflow.OPT_SCAN_FUSED_FINAL, 1)
+            r2 = e.diff(a, b, 10, 2.0)
+        assert_same(gx, wx, "flowx %dx%d %r" % (w, h, kw))
+        assert_same(gy, wy, "flowy %dx%d %r" % (w, h, kw))
+        want = oracle.span_scan(wx, wy, 10, 2.0)
+        assert r["vector"] == want and r2["vector"] == want, (h, w, kw)
+
+
 def test_pinned_and_pageable_callers_agree(twflow, oracle):
     """tw_submit_u8 from page-locked caller memory (DMA straight from it, also with a row stride) and from
     ordinary memory (staged) — same hits as the oracle; batches overlap on the copy stream."""
