@@ -180,6 +180,8 @@ void polyexp_setup(int n, double sigma, PolyCoef& pc)
         pc.g[k] = g[k];
         pc.xg[k] = xg[k];
         pc.xxg[k] = xxg[k];
+        pc.gd[k] = (double)g[k];
+        pc.xxgd[k] = (double)xxg[k];
     }
     pc.ig11 = B[1][1];
     pc.ig03 = B[0][3];
@@ -301,6 +303,7 @@ struct tw_engine {
     int scan_fused = 0;    // TW_OPT_SCAN_FUSED_FINAL
     int pyr_generic = 0;   // TW_PYR_GENERIC=1: always the generic pyramid kernel, 2: tw_pyr_level_lds for every level (A/B)
     int blur_variant = 4;  // 4: tw_blur_solve4 (default); 8: tw_blur_solve8 (packed f32) — TW_BLUR_VARIANT
+    int poly_variant = 1;  // 1: tw_polyexp_pk<N,8> (packed f32, default); 2: tw_polyexp_pk<N,16>; 0: tw_polyexp (scalar f32) — TW_POLY_VARIANT
     std::string err;
     // device workspace, shared by all batches (execution is ordered on one stream)
     size_t ws_elems = 0;                 // capacity of I (floats); R = 5x, M = 5x each
@@ -691,16 +694,34 @@ tw_status launch_polyexp(tw_engine* e, hipStream_t st, int w, int h, int ld, lon
     a.c = e->pc;
     dim3 grid((w + PE_TW - 1) / PE_TW, (h + PE_TH - 1) / PE_TH, nimg);
     ProfScope pscope(e, st, TW_K_POLYEXP, level);
+    if (e->poly_variant == 0) {
+        // scalar-f32 kernel (A/B: TW_POLY_VARIANT=0)
+        switch (e->p.polyN) {
+            case 1: hipLaunchKernelGGL(tw_polyexp<1>, grid, dim3(256), 0, st, a); break;
+            case 2: hipLaunchKernelGGL(tw_polyexp<2>, grid, dim3(256), 0, st, a); break;
+            case 3: hipLaunchKernelGGL(tw_polyexp<3>, grid, dim3(256), 0, st, a); break;
+            case 4: hipLaunchKernelGGL(tw_polyexp<4>, grid, dim3(256), 0, st, a); break;
+            case 5: hipLaunchKernelGGL(tw_polyexp<5>, grid, dim3(256), 0, st, a); break;
+            case 6: hipLaunchKernelGGL(tw_polyexp<6>, grid, dim3(256), 0, st, a); break;
+            case 7: hipLaunchKernelGGL(tw_polyexp<7>, grid, dim3(256), 0, st, a); break;
+            default: e->err = "polyN must be 1..7"; return TW_E_UNSUPPORTED;
+        }
+        return TW_OK;
+    }
+    // packed-f32 kernel, 240 x 8 tiles; TW_POLY_VARIANT=2 selects 240 x 16 tiles (960 two-by-two items = 15 full
+    // waves of the horizontal pass, 30-row window per 16 output rows, 48 KB LDS: measured equal within the noise)
+    const bool t16 = e->poly_variant == 2;
+    if (t16) grid.y = (h + 15) / 16;
+#define TW_PK_CASE(n)                                                                        \
+    case n:                                                                                  \
+        if (t16) hipLaunchKernelGGL((tw_polyexp_pk<n, 16>), grid, dim3(256), 0, st, a);      \
+        else hipLaunchKernelGGL((tw_polyexp_pk<n, 8>), grid, dim3(256), 0, st, a);           \
+        break;
     switch (e->p.polyN) {
-        case 1: hipLaunchKernelGGL(tw_polyexp<1>, grid, dim3(256), 0, st, a); break;
-        case 2: hipLaunchKernelGGL(tw_polyexp<2>, grid, dim3(256), 0, st, a); break;
-        case 3: hipLaunchKernelGGL(tw_polyexp<3>, grid, dim3(256), 0, st, a); break;
-        case 4: hipLaunchKernelGGL(tw_polyexp<4>, grid, dim3(256), 0, st, a); break;
-        case 5: hipLaunchKernelGGL(tw_polyexp<5>, grid, dim3(256), 0, st, a); break;
-        case 6: hipLaunchKernelGGL(tw_polyexp<6>, grid, dim3(256), 0, st, a); break;
-        case 7: hipLaunchKernelGGL(tw_polyexp<7>, grid, dim3(256), 0, st, a); break;
+        TW_PK_CASE(1) TW_PK_CASE(2) TW_PK_CASE(3) TW_PK_CASE(4) TW_PK_CASE(5) TW_PK_CASE(6) TW_PK_CASE(7)
         default: e->err = "polyN must be 1..7"; return TW_E_UNSUPPORTED;
     }
+#undef TW_PK_CASE
     return TW_OK;
 }
 
@@ -1175,6 +1196,7 @@ tw_status tw_engine_create(int device, const tw_params* params, int slots, tw_en
     e->box = (p.flags & 256) ? 0 : 1;
     if (const char* ev = getenv("TW_BLUR_VARIANT")) e->blur_variant = atoi(ev);
     if (const char* ev = getenv("TW_PYR_GENERIC")) e->pyr_generic = atoi(ev);
+    if (const char* ev = getenv("TW_POLY_VARIANT")) e->poly_variant = atoi(ev);
     if (const char* ev = getenv("TW_UPD_NY")) e->upd_ny = atoi(ev) == 1 ? 1 : 2;
     if (const char* ev = getenv("TW_LANES")) e->lanes = std::min(2, std::max(1, atoi(ev)));
     bool ok = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) == hipSuccess &&
@@ -1534,6 +1556,8 @@ extern "C" int tw_debug_occupancy(char* buf, int cap)
     add("tw_blur_solve8<15,256>", (const void*)tw_blur_solve8<15, 256, 16, 8, true, true>, 256, 0);
     add("tw_blur_solve8<15,128>", (const void*)tw_blur_solve8<15, 128, 16, 8, true, true>, 128, 0);
     add("tw_polyexp<7>", (const void*)tw_polyexp<7>, 256, 0);
+    add("tw_polyexp_pk<7,16>", (const void*)tw_polyexp_pk<7, 16>, 256, 0);
+    add("tw_polyexp_pk<7,8>", (const void*)tw_polyexp_pk<7, 8>, 256, 0);
     add("tw_update_matrices<true,2>", (const void*)tw_update_matrices<true, 2>, 256, 0);
     add("tw_pyr_k3<0>", (const void*)tw_pyr_k3<0>, 256, 0);
     return n;

@@ -706,6 +706,7 @@ constexpr int PE_TW = 240, PE_TH = 8, PE_COLS = 256, PE_HALO = 8;
 struct PolyCoef {
     float g[8], xg[8], xxg[8];  // index k = 0..N
     double ig11, ig03, ig33, ig55;
+    double gd[8], xxgd[8];  // (double)g[k], (double)xxg[k]: f64 operands straight from SGPR pairs (no VALU convert)
 };
 
 struct PolyArgs {
@@ -816,6 +817,219 @@ __global__ __launch_bounds__(256) void tw_polyexp(PolyArgs a)
                     d[j + 3 * a.ps] = o3[j];
                     d[j + 4 * a.ps] = o4[j];
                 }
+        }
+    }
+}
+
+// -----------------------------------------------------------------------------------------------------
+// tw_polyexp_pk<N> : the same arithmetic with every float add/sub/mul issued as a packed-f32 instruction
+//   (v_pk_add_f32 / v_pk_mul_f32 do two lanes' worth of IEEE f32 work in one issue slot; no contraction, so the
+//   bits are those of the scalar kernel).  The f64 part (v_cvt_f64_f32, v_add_f64, v_fma_f64) has no packed form
+//   and stays as it is.  Pairs are always the two ROWS (2p, 2p+1) of one column:
+//     V : one column per lane; the TH+2N window rows are held twice, as even-aligned pairs {w[2j], w[2j+1]} and as
+//         the pairs shifted by one row {w[2j+1], w[2j+2]} (each row is loaded into both sets: loads cost no VALU
+//         issue, a register copy would), so every tap of an output row pair is one aligned register pair;
+//         the three moment rows go to LDS as float2 {row 2p, row 2p+1} per column (ds_write_b64)
+//     H : an item = 2 columns x 2 rows; its 18-column window of a plane is 9 ds_read_b128 of aligned float2 pairs;
+//         planes are processed one after the other (moment 0 -> b1,b4,b2; moment 1 -> b3,b6; moment 2 -> b5) so
+//         that one window and at most 12 double accumulators are live
+// -----------------------------------------------------------------------------------------------------
+template <int N, int TH>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) void tw_polyexp_pk(PolyArgs a)
+{
+    constexpr int RP = TH / 2, NW = TH + 2 * N, NPA = NW / 2, NPB = NW / 2 - 1;
+    static_assert(NW % 2 == 0 && PE_TW % 2 == 0 && N <= PE_HALO - 1, "tile shape");
+    __shared__ __attribute__((aligned(16))) f32x2 sm[3][RP][PE_COLS];
+    const int tid = threadIdx.x;
+    int bx, by, bz;
+    xcd_remap(bx, by, bz);
+    const int x0 = bx * PE_TW, y0 = by * TH;
+    const float* __restrict__ src = a.src + bz * a.ps;
+    float* __restrict__ dst = a.dst + bz * 5 * a.ps;
+    const PolyCoef& c = a.c;
+
+    // ---- V ----
+    {
+        const unsigned xb = (unsigned)clampi(x0 - PE_HALO + tid, 0, a.w - 1) * 4u;
+        unsigned xb2 = xb;
+        asm volatile("" : "+v"(xb2));  // opaque copy: the second load of a row is not merged with the first
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(src);
+        f32x2 pa[NPA], pb[NPB > 0 ? NPB : 1];
+#pragma unroll
+        for (int i = 0; i < NW; i++) {
+            const unsigned ro = (unsigned)clampi(y0 - N + i, 0, a.h - 1) * ((unsigned)a.ld * 4u);
+            pa[i >> 1][i & 1] = bload(rs, xb, ro);
+            if (i >= 1 && i <= NW - 2) pb[(i - 1) >> 1][(i - 1) & 1] = bload(rs, xb2, ro);
+        }
+        // pair of window rows (t, t+1)
+        auto P = [&](int t) -> f32x2 { return (t & 1) ? pb[t >> 1] : pa[t >> 1]; };
+#pragma unroll
+        for (int rp = 0; rp < RP; rp++) {
+            const int ci = 2 * rp + N;
+            f32x2 t0 = P(ci) * c.g[0], t1 = f32x2{0.f, 0.f}, t2 = f32x2{0.f, 0.f};
+#pragma unroll
+            for (int k = 1; k <= N; k++) {
+                const f32x2 s0 = P(ci - k), s1 = P(ci + k);  // rows y-k, y+k
+                const f32x2 p = s0 + s1;
+                const f32x2 d = s1 - s0;
+                t0 = t0 + c.g[k] * p;
+                t1 = t1 + c.xg[k] * d;
+                t2 = t2 + c.xxg[k] * p;
+            }
+            sm[0][rp][tid] = t0;
+            sm[1][rp][tid] = t1;
+            sm[2][rp][tid] = t2;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    __syncthreads();
+
+    // ---- H: items = RP row pairs x 120 column pairs ----
+    constexpr int CPAIRS = PE_TW / 2;
+    constexpr int WL = 2 + 2 * PE_HALO;  // LDS columns 2cp .. 2cp+17; pixel j of the item sits at window index HALO+j
+    for (int it = tid; it < RP * CPAIRS; it += 256) {
+        const int rp = it / CPAIRS, cp = it - rp * CPAIRS;
+        const int y = y0 + 2 * rp, x = x0 + 2 * cp;
+        if (y >= a.h || x >= a.w) continue;
+        f32x2 v[WL];
+        auto load_window = [&](int pl) {
+#pragma unroll
+            for (int u = 0; u < WL / 2; u++) {
+                const f32x4 A = *(const f32x4*)&sm[pl][rp][2 * cp + 2 * u];
+                v[2 * u] = f32x2{A[0], A[1]};
+                v[2 * u + 1] = f32x2{A[2], A[3]};
+            }
+        };
+        f32x2 o[5][2];    // [plane][row q] = {pixel 0, pixel 1}
+        double p03[2][2];  // b1*ig03 of [pixel][row]
+        // (the two pixels and the two rows advance in lockstep, one tap at a time: 12 independent f64 chains)
+        // moment 0: b1, b4, b2
+        __builtin_amdgcn_sched_barrier(0);
+        load_window(0);
+        {
+            double b1[2][2], b2[2][2], b4[2][2];
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                f32x2 c0 = v[PE_HALO + j] * c.g[0];
+                asm("" : "+v"(c0));  // keep the packed multiply (both halves are only ever read one by one)
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    b1[j][q] = (double)c0[q];
+                    b2[j][q] = 0;
+                    b4[j][q] = 0;
+                }
+            }
+#pragma unroll
+            for (int k = 1; k <= N; k++) {
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    const int li = PE_HALO + j;
+                    const f32x2 tg = v[li + k] + v[li - k];
+                    const f32x2 pd = (v[li + k] - v[li - k]) * c.xg[k];
+#pragma unroll
+                    for (int q = 0; q < 2; q++) {
+                        const double T = (double)tg[q];
+                        // T, gd, xxgd are floats widened to double: the products are exact, fma == mul+add
+                        b1[j][q] = __builtin_fma(T, c.gd[k], b1[j][q]);
+                        b4[j][q] = __builtin_fma(T, c.xxgd[k], b4[j][q]);
+                        b2[j][q] += (double)pd[q];
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    o[1][q][j] = (float)(b2[j][q] * c.ig11);
+                    p03[j][q] = b1[j][q] * c.ig03;
+                    o[3][q][j] = (float)(p03[j][q] + b4[j][q] * c.ig33);
+                }
+        }
+        // moment 1: b3, b6
+        __builtin_amdgcn_sched_barrier(0);
+        load_window(1);
+        {
+            double b3[2][2], b6[2][2];
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                f32x2 c0 = v[PE_HALO + j] * c.g[0];
+                asm("" : "+v"(c0));  // keep the packed multiply (both halves are only ever read one by one)
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    b3[j][q] = (double)c0[q];
+                    b6[j][q] = 0;
+                }
+            }
+#pragma unroll
+            for (int k = 1; k <= N; k++) {
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    const int li = PE_HALO + j;
+                    const f32x2 ps = (v[li + k] + v[li - k]) * c.g[k];
+                    const f32x2 pd = (v[li + k] - v[li - k]) * c.xg[k];
+#pragma unroll
+                    for (int q = 0; q < 2; q++) {
+                        b3[j][q] += (double)ps[q];
+                        b6[j][q] += (double)pd[q];
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    o[0][q][j] = (float)(b3[j][q] * c.ig11);
+                    o[4][q][j] = (float)(b6[j][q] * c.ig55);
+                }
+        }
+        // moment 2: b5
+        __builtin_amdgcn_sched_barrier(0);
+        load_window(2);
+        {
+            double b5[2][2];
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                f32x2 c0 = v[PE_HALO + j] * c.g[0];
+                asm("" : "+v"(c0));  // keep the packed multiply (both halves are only ever read one by one)
+#pragma unroll
+                for (int q = 0; q < 2; q++) b5[j][q] = (double)c0[q];
+            }
+#pragma unroll
+            for (int k = 1; k <= N; k++) {
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    const int li = PE_HALO + j;
+                    f32x2 ps = (v[li + k] + v[li - k]) * c.g[k];
+                    asm("" : "+v"(ps));  // as above: without this the pair is computed as four scalar instructions
+#pragma unroll
+                    for (int q = 0; q < 2; q++) b5[j][q] += (double)ps[q];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+                for (int q = 0; q < 2; q++) o[2][q][j] = (float)(p03[j][q] + b5[j][q] * c.ig33);
+        }
+        // every result is materialised here: left alone, LLVM sinks the chains of the second row / second pixel into
+        // the edge conditionals below (their halves of every packed value then wait in scratch)
+#pragma unroll
+        for (int pl = 0; pl < 5; pl++)
+#pragma unroll
+            for (int q = 0; q < 2; q++) asm volatile("" : "+v"(o[pl][q]));
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            if (y + q >= a.h) break;
+            float* d = dst + (long long)(y + q) * a.ld + x;
+            if (x + 1 < a.w) {
+#pragma unroll
+                for (int pl = 0; pl < 5; pl++) *(f32x2*)(d + pl * a.ps) = o[pl][q];
+            } else {
+#pragma unroll
+                for (int pl = 0; pl < 5; pl++) d[pl * a.ps] = o[pl][q][0];
+            }
         }
     }
 }
