@@ -155,10 +155,15 @@ tw_status tw_prof_select(tw_engine* e, int kclass, int level);
 /* Sum of event-measured milliseconds and number of launches of `kclass` since the last read; resets both.
  * Synchronises the device. */
 tw_status tw_prof_read(tw_engine* e, int kclass, double* ms_total, int* launches);
-/* Algorithmic bytes (SURVEY §8d model) of one launch of `kclass` at `level` for a w x h pair. */
+/* Bytes one launch of `kclass` at `level` must move for a w x h pair: every input of the kernel AS BUILT read once,
+ * every output written once (blur+solve: averaged over the pyrIterations launches of a level — a launch fused with
+ * the matrix refresh moves 80 B/px, the last one 28 B/px; flows that never leave the registers are not counted). */
 double tw_algorithmic_bytes(const tw_engine* e, int kclass, int level, int width, int height);
-/* Algorithmic bytes of one whole pair (sum over levels and stages, scan included). */
+/* SURVEY.md 8(d) model of one whole pair (each named stage of the reference reads its inputs once and writes its
+ * outputs once; 991.8 MB at 1080p with the defaults): the figure BASELINE.md prices a pair against. */
 double tw_algorithmic_bytes_pair(const tw_engine* e, int width, int height, int span);
+/* Sum of tw_algorithmic_bytes over every launch of a pair: what the fused kernels must move (859.6 MB at 1080p). */
+double tw_min_traffic_bytes_pair(const tw_engine* e, int width, int height, int span);
 /* Number of pyramid levels (= index of the coarsest level) the engine uses for w x h. */
 int tw_num_levels(const tw_engine* e, int width, int height);
 /* Image pairs one kernel launch covers at `level` (the level-major batch schedule), -1 on error. */

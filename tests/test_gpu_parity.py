@@ -491,3 +491,47 @@ def test_strided_input_and_errors(engine, twflow, oracle):
     with pytest.raises(twflow.TwError) as ei:
         engine.calculate_internal(a.astype(np.float32), b.astype(np.float32))
     assert ei.value.code == twflow.TW_E_BAD_IMAGE_FORMAT
+
+
+def test_failed_batch_launch_does_not_wedge_the_engine(twflow, oracle):
+    """a batch whose launch fails (here: a pyramid level whose smoothing kernel exceeds the supported
+    size, TW_E_UNSUPPORTED at plan time) must be dropped, not re-flushed by every later submit.  slots=1 makes the
+    failing submit the one that launches."""
+    kw = dict(pyrScale=0.015, pyrLevels=1)
+    rng = np.random.default_rng(77)
+    big = rng.integers(0, 256, (2200, 2200), dtype=np.uint8)
+    a = rand_img(rng, 64, 64)
+    b = np.roll(a, 1, axis=1)
+    want = oracle.farneback(a, b, oracle.default_params(**kw))
+    for slots in (1, 2):
+        with twflow.Engine(0, twflow.default_params(**kw), slots=slots) as e:
+            with pytest.raises(twflow.TwError) as ei:
+                t = e.submit(big, big)
+                e.wait(t)  # slots=2: the batch is still open, the failure surfaces at the wait
+            assert ei.value.code == twflow.TW_E_UNSUPPORTED
+            for _ in range(3):  # the engine still works, for the same and for later batches
+                r = e.diff(a, b, 4, 0.5)
+                assert r["vector"] == oracle.span_scan(want[0], want[1], 4, 0.5)
+            gx, gy, _ = e.calculate_internal(a, b)
+            assert_same(gx, want[0], "flowx after a failed batch")
+            with pytest.raises(twflow.TwError):
+                e.diff(big, big)
+            assert e.diff(a, b, 4, 0.5)["vector"] == oracle.span_scan(want[0], want[1], 4, 0.5)
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(flags=0), dict(flags=0, winSize=13)])
+def test_two_stream_lanes_gaussian_and_box(twflow, oracle, kw, monkeypatch):
+    """TW_LANES=2 (the halves of a batch on two streams): each lane owns its slice of every workspace, the box
+    window's double column sums included.  Four pairs in one batch, every vector list exact."""
+    monkeypatch.setenv("TW_LANES", "2")
+    rng = np.random.default_rng(31)
+    imgs = []
+    for i in range(4):
+        a = rand_img(rng, 140, 230)
+        imgs.append((a, np.roll(a, 1 + i, axis=i % 2)))
+    with twflow.Engine(0, twflow.default_params(**kw), slots=4) as e:
+        tk = [e.submit(a, b, 5, 0.75) for a, b in imgs]
+        got = [e.wait(t)["vector"] for t in tk]
+    for (a, b), g in zip(imgs, got):
+        wx, wy = oracle.farneback(a, b, oracle.default_params(**kw))
+        assert g == oracle.span_scan(wx, wy, 5, 0.75)

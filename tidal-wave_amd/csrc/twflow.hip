@@ -726,7 +726,7 @@ tw_status launch_polyexp(tw_engine* e, hipStream_t st, int w, int h, int ld, lon
 }
 
 void launch_blur(tw_engine* e, hipStream_t st, int w, int h, int ld, long long ps, const float* Min, float* Mout,
-                 float* flow, const float* R, int update, int level, int npairs)
+                 float* flow, const float* R, int update, int level, int npairs, double* Vbox = nullptr)
 {
     BlurArgs a;
     a.Min = Min;
@@ -748,7 +748,7 @@ void launch_blur(tw_engine* e, hipStream_t st, int w, int h, int ld, long long p
     const bool wide = w > 480;  // 224-column tiles; narrow levels use 96-column tiles (less edge waste)
     if (e->box) {
         // box window: sequential double running sums (two scan kernels) + the standard refresh kernel
-        double* V = e->Vd;
+        double* V = Vbox ? Vbox : e->Vd;  // TW_LANES=2: each lane (stream) has its own column sums
         Tmp tmp;
         if (level < 0) {  // per-stage test entry: no engine workspace
             V = tmp.alloc<double>((size_t)ps * 5 * npairs);
@@ -942,7 +942,7 @@ tw_status flush_ctx(tw_engine* e, Ctx& c)
                         break;
                     }
                     launch_blur(e, ls, L.w, L.h, L.ld, L.ps, (i & 1) ? M1 : M0, (i & 1) ? M0 : M1, flow_cur, R,
-                                i < it - 1, k, nc);
+                                i < it - 1, k, nc, e->Vd ? e->Vd + ws_lane / 2 * 5 * lane : nullptr);
                 }
                 if (k == 0 && c.span > 0 && !grid_only) {
                     // grid samples of this chunk -> dense per-pair buffer (the ordered scan runs once per batch)
@@ -1035,7 +1035,13 @@ tw_status submit_common(tw_engine* e, const uint8_t* h_a, const uint8_t* h_b, co
     const bool fits = open && c->w == width && c->h == height && c->span == span && c->threshold == threshold &&
                       c->jobs[0].stride == eff_stride && (int)c->jobs.size() < e->cap;
     if (!fits) {
-        if (open && (r = flush_ctx(e, *c))) return r;
+        if (open && (r = flush_ctx(e, *c))) {
+            // the open batch cannot run (unsupported plan, out of memory): drop it as tw_wait does, so that the
+            // engine stays usable; its tickets answer "unknown ticket"
+            c->pending = 0;
+            c->jobs.clear();
+            return r;
+        }
         if (c->pending > 0) {  // still owed to the caller: move on to the next context
             const int nxt = (e->cur + 1) % NCTX;
             if (e->ctx[nxt].pending > 0) return TW_E_BUSY;
@@ -1105,7 +1111,11 @@ tw_status submit_common(tw_engine* e, const uint8_t* h_a, const uint8_t* h_b, co
     c->pending++;
     if (ticket) *ticket = e->next_ticket;
     e->next_ticket++;
-    if ((int)c->jobs.size() == e->cap) return flush_ctx(e, *c);
+    if ((int)c->jobs.size() == e->cap && (r = flush_ctx(e, *c))) {
+        c->pending = 0;  // as above: a batch that cannot be launched is dropped, not retried by every later submit
+        c->jobs.clear();
+        return r;
+    }
     return TW_OK;
 }
 
@@ -1489,23 +1499,56 @@ double tw_algorithmic_bytes(const tw_engine* e, int kclass, int level, int width
         case TW_K_PYR: return 2 * (N0 + 4 * N);
         case TW_K_POLYEXP: return 48 * N;  // 2 images x (4 + 20) B/px
         case TW_K_UPDATE_MATRICES: {
-            double up = 8 * N;  // memset at the coarsest level
+            // R0 20N + R1 20N read, M 20N written; the level's initial flow is read from the coarser level (8 N_{k+1})
+            // and is only stored when no iteration follows (the first blur launch recomputes nothing from it: the
+            // refresh of iteration 0 uses M, and the flow itself is rewritten by the first solve)
+            double up = it == 0 ? 8 * N : 0;
             if (level < L) {
                 int pw, ph;
                 level_geometry(width, height, e->p.pyrScale, level + 1, &pw, &ph, &sg, &ks, &sc);
-                up = 8.0 * pw * ph + 8 * N;
+                up += 8.0 * pw * ph;
             }
-            return 68 * N + up;
+            return 60 * N + up;
         }
         case TW_K_BLUR_SOLVE:
-            // average over the `it` launches of a level: every launch blurs+solves (28N); all but the
-            // last also refresh M (68N) inside the same kernel
-            return it > 0 ? (it * 28 * N + (it - 1) * 68 * N) / it : 0;
+            // average over the `it` launches of a level.  The last one reads M (20N) and writes the flow (8N).  The
+            // others are fused with the FarnebackUpdateMatrices refresh: M 20N + R0 20N + R1 20N read, M 20N
+            // written = 80N — the flow they compute stays in registers and is never stored (counting
+            // 28N + 68N charged 16N the kernel does not move).
+            return it > 0 ? (28 * N + (it - 1) * 80 * N) / it : 0;
         default: return 0;
     }
 }
 
+// SURVEY.md 8(d) model of one pair (every named stage of the reference reads each input once and writes each output
+// once: pyr 2(N0+4N), polyexp 48N, updateMatrices 68N and blur+solve 28N per iteration, flow init): the
+// figure BASELINE.md prices the pair against (991.8 MB at 1080p with the default parameters).
 double tw_algorithmic_bytes_pair(const tw_engine* e, int width, int height, int span)
+{
+    if (!e) return 0;
+    const int L = tw_num_levels(e, width, height);
+    const int it = e->p.pyrIterations;
+    double tot = 0;
+    for (int k = 0; k <= L; k++) {
+        int w, h, ks;
+        double sg, sc;
+        level_geometry(width, height, e->p.pyrScale, k, &w, &h, &sg, &ks, &sc);
+        const double N = (double)w * h, N0 = (double)width * height;
+        double up = 8 * N;  // memset at the coarsest level
+        if (k < L) {
+            int pw, ph;
+            level_geometry(width, height, e->p.pyrScale, k + 1, &pw, &ph, &sg, &ks, &sc);
+            up = 8.0 * pw * ph + 8 * N;
+        }
+        tot += 2 * (N0 + 4 * N) + 48 * N + up + it * (68 + 28) * N;
+    }
+    if (span > 0) tot += 16.0 * tw_grid_capacity(width, height, span);
+    return tot;
+}
+
+// What the kernels as built must move for one pair (fusion removed the flow stores between iterations): the sum of
+// tw_algorithmic_bytes over all launches.  Reported beside the SURVEY figure; smaller than it.
+double tw_min_traffic_bytes_pair(const tw_engine* e, int width, int height, int span)
 {
     if (!e) return 0;
     const int L = tw_num_levels(e, width, height);

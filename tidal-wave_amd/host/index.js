@@ -72,16 +72,22 @@ function calcAll(tidalwave, targetDir, getExpectedPath) {
       });
     }
   });
-  function done() { if (--pending === 0) globEnded = true; }
-
-  tidalwave.on('data', function() {
-    if (globEnded && --requested <= 0) {   // index.js:64-68 of the reference, verbatim semantics
-      tidalwave.dispose();
+  var disposed = false;
+  function disposeIfIdle() {
+    // every requested pair has answered and the walk is over: nothing else will arrive
+    if (globEnded && requested <= 0 && !disposed) { disposed = true; tidalwave.dispose(); }
+  }
+  function done() {
+    if (--pending === 0) {
+      globEnded = true;
+      disposeIfIdle();  // results that came in before the walk ended (or a walk that requested nothing)
     }
-  });
-  tidalwave.on('error', function() {
-    // the reference only decrements here (index.js:69-71), so a run whose last event is an error never
-    // finishes; disposing when nothing is outstanding fixes that without changing any successful run
-    if (--requested <= 0 && globEnded) tidalwave.dispose();
-  });
+  }
+
+  // The reference counts `requested` down only once the walk has ended (`globEnded && --requested <= 0`,
+  // index.js:64-68) and, on 'error', never checks for completion (index.js:69-71): an event that arrives before the
+  // last FS callback, or a run whose last event is an error, leaves the instance undisposed for ever.  With a
+  // millisecond-latency engine both happen, so every event is counted and completion is checked at every step.
+  tidalwave.on('data', function() { requested--; disposeIfIdle(); });
+  tidalwave.on('error', function() { requested--; disposeIfIdle(); });
 }

@@ -1,0 +1,83 @@
+// stub_twflow.cpp — a stand-in for libtwflow.so's C ABI that computes nothing: every pair answers a canned vector
+// list after a short sleep.  ONLY for the ThreadSanitizer build of the host layer (`make tsan`), which must run
+// on the CPU (GPU sanitizer runs are not available): it lets twhost.cpp's queue, consumers, pump and dispose path
+// run under TSAN with 8 consumers on 8 pretend devices.  Never linked into the product.
+#include <stdlib.h>
+#include <string.h>
+
+#include <atomic>
+#include <chrono>
+#include <map>
+#include <mutex>
+#include <thread>
+
+#include "../../include/twflow.h"
+
+struct tw_engine {
+    int device, cap;
+    std::mutex m;
+    std::map<tw_ticket, int> open;  // ticket -> width (echoed as the vector's x)
+    tw_ticket next = 1;
+};
+
+static std::atomic<int> g_engines{0};
+
+extern "C" {
+void tw_default_params(tw_params* p)
+{
+    p->pyrScale = 0.5; p->pyrLevels = 3; p->winSize = 30; p->pyrIterations = 3; p->polyN = 7; p->polySigma = 1.5; p->flags = 256;
+}
+int tw_device_count(void)
+{
+    const char* ev = getenv("TW_STUB_DEVICES");
+    return ev ? atoi(ev) : 8;
+}
+const char* tw_strerror(tw_status) { return "stub"; }
+const char* tw_last_error(const tw_engine*) { return ""; }
+int tw_grid_capacity(int w, int h, int span) { return span > 0 ? ((h + span - 1) / span) * ((w + span - 1) / span) : 0; }
+tw_status tw_engine_create(int device, const tw_params*, int slots, tw_engine** out)
+{
+    tw_engine* e = new tw_engine();
+    e->device = device;
+    e->cap = slots;
+    g_engines++;
+    *out = e;
+    return TW_OK;
+}
+void tw_engine_destroy(tw_engine* e)
+{
+    g_engines--;
+    delete e;
+}
+tw_status tw_submit_u8(tw_engine* e, const uint8_t* a, const uint8_t* b, int w, int h, ptrdiff_t, int, double, tw_ticket* t)
+{
+    if (!a || !b || w < 1 || h < 1) return TW_E_BAD_PARAMETER;
+    std::lock_guard<std::mutex> lk(e->m);
+    *t = e->next++;
+    e->open[*t] = w + (a[0] != b[0] ? 1000000 : 0);
+    return TW_OK;
+}
+tw_status tw_flush(tw_engine*) { return TW_OK; }
+tw_status tw_wait(tw_engine* e, tw_ticket t, tw_vector* out, int cap, int* n, float* seconds)
+{
+    int w;
+    {
+        std::lock_guard<std::mutex> lk(e->m);
+        auto it = e->open.find(t);
+        if (it == e->open.end()) return TW_E_BAD_PARAMETER;
+        w = it->second;
+        e->open.erase(it);
+    }
+    std::this_thread::sleep_for(std::chrono::microseconds(50));
+    const bool differs = w >= 1000000;
+    if (n) *n = differs ? 1 : 0;
+    if (differs && out && cap > 0) {
+        out[0].x = w - 1000000;
+        out[0].y = e->device;
+        out[0].dx = 6.0;
+        out[0].dy = -7.5;
+    }
+    if (seconds) *seconds = 1e-4f;
+    return TW_OK;
+}
+}

@@ -4,6 +4,7 @@
 
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <zlib.h>
 
@@ -251,8 +252,9 @@ void resize_u8_linear(const std::vector<uint8_t>& src, int sw, int sh, std::vect
 // Consumer
 // ---------------------------------------------------------------------------------------------------
 Consumer::Consumer(int id, MessageQueue<Request>& req, MessageQueue<Response>& res, const tw_params& p, int batch,
-                   int decode_threads)
-    : id_(id), req_(req), res_(res), params_(p), batch_(std::max(1, batch)), decode_threads_(std::max(1, decode_threads))
+                   int decode_threads, int n_consumers)
+    : id_(id), req_(req), res_(res), params_(p), batch_(std::max(1, batch)), decode_threads_(std::max(1, decode_threads)),
+      n_consumers_(std::max(1, n_consumers))
 {
 }
 Consumer::~Consumer() { join(); }
@@ -266,6 +268,8 @@ namespace {
 struct Staged {
     Request req;
     std::vector<uint8_t> a, b;
+    const uint8_t *pa = nullptr, *pb = nullptr;  // the pair as handed to the engine (a/b or the caller's raw buffers)
+    ptrdiff_t stride = 0;
     int w = 0, h = 0;
     std::string err;
     tw_ticket ticket = 0;
@@ -276,6 +280,16 @@ struct Staged {
 // OpticalFlow::calculate up to (not including) calculateInternal: src/opticalflow.cpp:20-68
 void prepare(Staged& s)
 {
+    if (s.req.raw.expect) {  // in-memory pair: nothing to decode
+        const RawPair& r = s.req.raw;
+        if (!r.target || r.width < 1 || r.height < 1 || r.stride < r.width) { s.err = "bad raw image pair"; return; }
+        s.pa = r.expect;
+        s.pb = r.target;
+        s.w = r.width;
+        s.h = r.height;
+        s.stride = r.stride;
+        return;
+    }
     if (s.req.expect_image.empty()) { s.err = "ExpectImagePath is empty."; return; }
     if (s.req.target_image.empty()) { s.err = "TargetImagePath is empty."; return; }
     int tw = 0, th = 0;
@@ -287,6 +301,9 @@ void prepare(Staged& s)
         resize_u8_linear(s.b, tw, th, r, s.w, s.h);
         s.b.swap(r);
     }
+    s.pa = s.a.data();
+    s.pb = s.b.data();
+    s.stride = s.w;
 }
 }  // namespace
 
@@ -303,12 +320,61 @@ void Consumer::run()
     } else {
         eng_err = "no HIP device available";
     }
-    Request first;
-    while (req_.tryPop(first)) {
+    // wait for one job and hand its response to the pump
+    auto finish = [&](Staged& s) {
+        if (s.done) return;
+        s.done = true;
+        Response res;
+        if (s.submitted) {
+            const int cap = std::max(1, tw_grid_capacity(s.w, s.h, s.req.span));
+            std::vector<tw_vector> v((size_t)cap);
+            int n = 0;
+            float sec = 0;
+            tw_status r = tw_wait(eng, s.ticket, v.data(), cap, &n, &sec);
+            if (r != TW_OK) {
+                s.err = std::string(tw_last_error(eng)[0] ? tw_last_error(eng) : tw_strerror(r));
+            } else {
+                res.vectors.resize((size_t)std::min(n, cap));
+                for (size_t i = 0; i < res.vectors.size(); i++) res.vectors[i] = {v[i].x, v[i].y, v[i].dx, v[i].dy};
+                res.status = res.vectors.empty() ? "OK" : "SUSPICIOUS";  // src/consumer.cpp:77
+                res.time = sec;
+                res.expect_image = s.req.expect_image;
+                res.target_image = s.req.target_image;
+                res.span = s.req.span;
+                res.threshold = s.req.threshold;
+                res.height = s.h;
+                res.width = s.w;
+            }
+        }
+        if (!s.err.empty()) {
+            res = Response();
+            res.status = "ERROR";  // src/consumer.cpp:85-88
+            res.reason = s.err;
+        }
+        res_.push(std::move(res));
+    };
+    // Two batches are kept going: the one just submitted computes while the next one is popped, decoded and
+    // uploaded (the engine itself holds up to three batches).  Responses leave in completion order, as in the
+    // reference.
+    std::vector<Staged> prev;
+    auto finish_all = [&](std::vector<Staged>& v) {
+        for (Staged& s : v) finish(s);
+        v.clear();
+    };
+    for (;;) {
+        Request first;
+        if (!req_.tryPopNow(first)) {
+            finish_all(prev);  // nothing queued: deliver what is outstanding before blocking
+            if (!req_.tryPop(first)) break;
+        }
         std::vector<Staged> jobs(1);
         jobs[0].req = std::move(first);
+        // a consumer takes at most its share of what is queued, so that a short queue is spread over all GPUs
+        // (a greedy grab of `batch` jobs starves the other consumers)
+        const size_t share = (req_.size() + 1 + (size_t)n_consumers_ - 1) / (size_t)n_consumers_;
+        const size_t take = std::max<size_t>(1, std::min<size_t>((size_t)batch_, share));
         Request more;
-        while ((int)jobs.size() < batch_ && req_.tryPopNow(more)) {
+        while (jobs.size() < take && req_.tryPopNow(more)) {
             jobs.emplace_back();
             jobs.back().req = std::move(more);
         }
@@ -330,55 +396,28 @@ void Consumer::run()
         std::stable_sort(jobs.begin(), jobs.end(), [](const Staged& x, const Staged& y) {
             return x.w != y.w ? x.w < y.w : x.h < y.h;
         });
-        // wait for one job and hand its response to the pump
-        auto finish = [&](Staged& s) {
-            if (s.done) return;
-            s.done = true;
-            Response res;
-            if (s.submitted) {
-                const int cap = std::max(1, tw_grid_capacity(s.w, s.h, s.req.span));
-                std::vector<tw_vector> v((size_t)cap);
-                int n = 0;
-                float sec = 0;
-                tw_status r = tw_wait(eng, s.ticket, v.data(), cap, &n, &sec);
-                if (r != TW_OK) {
-                    s.err = std::string(tw_last_error(eng)[0] ? tw_last_error(eng) : tw_strerror(r));
-                } else {
-                    res.vectors.resize((size_t)std::min(n, cap));
-                    for (size_t i = 0; i < res.vectors.size(); i++) res.vectors[i] = {v[i].x, v[i].y, v[i].dx, v[i].dy};
-                    res.status = res.vectors.empty() ? "OK" : "SUSPICIOUS";  // src/consumer.cpp:77
-                    res.time = sec;
-                    res.expect_image = s.req.expect_image;
-                    res.target_image = s.req.target_image;
-                    res.span = s.req.span;
-                    res.threshold = s.req.threshold;
-                    res.height = s.h;
-                    res.width = s.w;
-                }
-            }
-            if (!s.err.empty()) {
-                res = Response();
-                res.status = "ERROR";  // src/consumer.cpp:85-88
-                res.reason = s.err;
-            }
-            res_.push(std::move(res));
-        };
         for (size_t k = 0; k < jobs.size(); k++) {
             Staged& s = jobs[k];
             if (s.err.empty() && !eng) s.err = eng_err;
             if (!s.err.empty()) continue;
-            tw_status r = tw_submit_u8(eng, s.a.data(), s.b.data(), s.w, s.h, s.w, s.req.span, s.req.threshold, &s.ticket);
+            tw_status r = tw_submit_u8(eng, s.pa, s.pb, s.w, s.h, s.stride, s.req.span, s.req.threshold, &s.ticket);
             if (r == TW_E_BUSY) {
                 // every batch context of the engine is owed to us (each size change opens one): collect what
                 // is outstanding, then this job starts a fresh batch
+                finish_all(prev);
                 for (size_t q = 0; q < k; q++) finish(jobs[q]);
-                r = tw_submit_u8(eng, s.a.data(), s.b.data(), s.w, s.h, s.w, s.req.span, s.req.threshold, &s.ticket);
+                r = tw_submit_u8(eng, s.pa, s.pb, s.w, s.h, s.stride, s.req.span, s.req.threshold, &s.ticket);
             }
             if (r == TW_OK) s.submitted = true;
             else s.err = std::string(tw_last_error(eng)[0] ? tw_last_error(eng) : tw_strerror(r));
         }
-        for (Staged& s : jobs) finish(s);
+        if (eng) (void)tw_flush(eng);  // a partly filled batch starts now, not when its first result is asked for
+        for (Staged& s : jobs)
+            if (!s.submitted) finish(s);  // errors do not wait for the GPU
+        finish_all(prev);
+        prev = std::move(jobs);
     }
+    finish_all(prev);
     if (eng) tw_engine_destroy(eng);
 }
 
@@ -397,16 +436,21 @@ void Manager::start(const Parameter& p)
     param_ = p;
     running_ = true;
     const int ndev = tw_device_count();
-    // numThreads consumers as in src/manager.cpp:55-59; more consumers than GPUs would only time-share a
-    // device, so the surplus is folded into the per-consumer batch instead
-    const int n = std::max(1, ndev > 0 ? std::min(p.numThreads, ndev) : 1);
-    const int batch = std::max(1, std::min(32, p.numThreads * 2));
+    // numThreads consumers as in src/manager.cpp:55-59, at most `perDevice` of them per GPU (default 1: more
+    // consumers than GPUs only time-share a device, the surplus is folded into the per-consumer batch instead;
+    // TW_CONSUMERS_PER_DEVICE / Parameter::consumersPerDevice raise it — consumer i runs on device i % ndev)
+    int per_dev = p.consumersPerDevice;
+    if (per_dev <= 0)
+        if (const char* ev = getenv("TW_CONSUMERS_PER_DEVICE")) per_dev = atoi(ev);
+    if (per_dev <= 0) per_dev = 1;
+    const int n = std::max(1, ndev > 0 ? std::min(p.numThreads, ndev * per_dev) : 1);
+    const int batch = p.batch > 0 ? std::min(256, p.batch) : std::max(1, std::min(32, p.numThreads * 2));
     // decode threads per consumer: TW_DECODE_THREADS, else the host cores shared between the consumers
     int dec = 0;
     if (const char* ev = getenv("TW_DECODE_THREADS")) dec = atoi(ev);
     if (dec <= 0) dec = std::max(1, std::min(16, (int)std::thread::hardware_concurrency() / n));
     for (int i = 0; i < n; i++) {
-        consumers_.push_back(new Consumer(i, requestQueue_, responseQueue_, p.optParam, batch, dec));
+        consumers_.push_back(new Consumer(i, requestQueue_, responseQueue_, p.optParam, batch, dec, n));
         consumers_.back()->start();
     }
     pump_ = std::thread([this] { work(); });
@@ -419,6 +463,22 @@ int Manager::request(const std::string& expect_image, const std::string& target_
     r.target_image = target_image;
     r.span = param_.span;
     r.threshold = param_.threshold;
+    {
+        std::lock_guard<std::mutex> lk(report_m_);
+        report_.requestCount++;
+    }
+    requestQueue_.push(std::move(r));
+    return 0;
+}
+
+int Manager::requestRaw(const std::string& expect_name, const std::string& target_name, const RawPair& raw)
+{
+    Request r;
+    r.expect_image = expect_name;
+    r.target_image = target_name;
+    r.span = param_.span;
+    r.threshold = param_.threshold;
+    r.raw = raw;
     {
         std::lock_guard<std::mutex> lk(report_m_);
         report_.requestCount++;

@@ -15,12 +15,23 @@
 
 namespace twhost {
 
+// An image pair that is already decoded, in the caller's memory (8-bit gray, row stride in bytes).  Not part of
+// the reference's Request: the throughput driver (tools/bench_queue.cpp, BASELINE config 4) uses it to feed the
+// manager queue without touching the file system.  The buffers stay valid until the pair's response arrives;
+// page-locked buffers (tw_host_alloc) are DMA-ed from directly.
+struct RawPair {
+    const uint8_t* expect = nullptr;
+    const uint8_t* target = nullptr;
+    int width = 0, height = 0;
+    ptrdiff_t stride = 0;
+};
 // /root/reference/src/message_queue.h:13-48
 struct Request {
     std::string expect_image;
     std::string target_image;
     double threshold;
     int span;
+    RawPair raw;  // raw.expect != nullptr: the paths above are labels only
 };
 struct Vector {
     int x, y;
@@ -45,6 +56,10 @@ struct Parameter {
     int span = 10;
     int numThreads = 4;
     tw_params optParam;
+    // not in the reference: consumers that share one GPU (0: TW_CONSUMERS_PER_DEVICE, default 1) and the engine
+    // batch of a consumer (0: min(32, 2*numThreads)).  The consumer count is min(numThreads, devices * perDevice).
+    int consumersPerDevice = 0;
+    int batch = 0;
 };
 
 // Blocking MPMC queue, MessageQueue<T> of src/message_queue.h:50-118 (stop() wakes every waiter; as in the
@@ -86,6 +101,11 @@ public:
         }
         cv_.notify_all();
     }
+    size_t size()
+    {
+        std::lock_guard<std::mutex> lk(m_);
+        return q_.size();
+    }
 
 private:
     std::mutex m_;
@@ -115,7 +135,7 @@ struct Observer {
 class Consumer {
 public:
     Consumer(int id, MessageQueue<Request>& req, MessageQueue<Response>& res, const tw_params& p, int batch,
-             int decode_threads);
+             int decode_threads, int n_consumers = 1);
     ~Consumer();
     void start();
     void join();
@@ -128,6 +148,7 @@ private:
     tw_params params_;
     int batch_;
     int decode_threads_;  // images of a batch are decoded by this many threads
+    int n_consumers_;     // consumers on the same request queue: a consumer leaves the others their share of a short queue
     std::thread th_;
 };
 
@@ -139,6 +160,9 @@ public:
     ~Manager();
     void start(const Parameter& p);
     int request(const std::string& expect_image, const std::string& target_image);
+    // the same for an in-memory pair (see RawPair); the two names are only echoed in the response
+    int requestRaw(const std::string& expect_name, const std::string& target_name, const RawPair& raw);
+    int consumerCount() const { return (int)consumers_.size(); }
     void stop();  // idempotent; completion is reported through onCompleted
     bool running() const { return running_; }
 

@@ -51,7 +51,7 @@ SYMBOLS = [
     "tw_last_error", "tw_flow_u8", "tw_diff_u8", "tw_submit_u8", "tw_submit_dev", "tw_flush", "tw_wait",
     "tw_grid_capacity", "tw_dev_alloc", "tw_dev_free", "tw_dev_upload", "tw_host_alloc", "tw_host_free", "tw_set_option",
     "tw_prof_select", "tw_prof_read",
-    "tw_algorithmic_bytes", "tw_algorithmic_bytes_pair", "tw_num_levels", "tw_level_chunk", "tw_bench_stage", "tw_stage_pyr_level",
+    "tw_algorithmic_bytes", "tw_algorithmic_bytes_pair", "tw_min_traffic_bytes_pair", "tw_num_levels", "tw_level_chunk", "tw_bench_stage", "tw_stage_pyr_level",
     "tw_stage_polyexp", "tw_stage_update_matrices", "tw_stage_flow_upsample_update", "tw_stage_blur_solve",
 ]
 
@@ -99,6 +99,8 @@ def lib():
     L.tw_algorithmic_bytes.restype = C.c_double
     L.tw_algorithmic_bytes_pair.argtypes = [vp, C.c_int, C.c_int, C.c_int]
     L.tw_algorithmic_bytes_pair.restype = C.c_double
+    L.tw_min_traffic_bytes_pair.argtypes = [vp, C.c_int, C.c_int, C.c_int]
+    L.tw_min_traffic_bytes_pair.restype = C.c_double
     L.tw_num_levels.argtypes = [vp, C.c_int, C.c_int]
     L.tw_stage_pyr_level.argtypes = [vp, u8p, C.c_int, C.c_int, C.c_int, fp, ip, ip]
     L.tw_stage_polyexp.argtypes = [vp, fp, C.c_int, C.c_int, fp]
@@ -290,6 +292,9 @@ class Engine:
 
     def algorithmic_bytes_pair(self, w, h, span):
         return self._L.tw_algorithmic_bytes_pair(self._h, w, h, span)
+
+    def min_traffic_bytes_pair(self, w, h, span):
+        return self._L.tw_min_traffic_bytes_pair(self._h, w, h, span)
 
     def num_levels(self, w, h):
         return self._L.tw_num_levels(self._h, w, h)
