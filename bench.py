@@ -17,13 +17,25 @@ The JSON line also carries
   roofline_polyexp   the same for tw_polyexp @ level 0 (the kernel BASELINE.json grades)
   cpu_baseline  the CPU oracle (a scalar port of OpenCV 2.4.9's algorithm; OpenCV itself is not
                 installable here) timed on this box's host cores on a bounded sample — rank 0, N=1 only
+  config3_host_pinned   BASELINE.json configs[2]: 256 x 1080p pairs handed over as page-locked HOST buffers
+                (tw_host_alloc), uploads on the engine's copy stream overlapped with the previous batch's kernels,
+                only the hits come back — wall-clock pairs/s, PCIe included (reference: src/opticalflow.cpp:100,115-116)
+  config5_4k    BASELINE.json configs[4] on one GPU: 3840x2160, pyrLevels 5, winSize 50, iters 5, resident in HBM
+  queue_sharded BASELINE.json configs[3]'s shape: in-memory pairs through ONE twhost::Manager queue with one
+                consumer per device (tools/bench_queue.cpp; reference src/manager.cpp:55-59,68-78)
+All three are measured outside the timed region, on rank 0 at N=1, and are never `value`.
+`python bench.py --gpus N` WITHOUT torchrun (no WORLD_SIZE in the environment) runs the queue-sharded driver on N
+devices of this box as the whole job: one process, N consumers on one queue, 256 pairs per device.
 The oracle is used here only as the cpu_baseline leg and to check one result; it is never the thing
 measured as `value`.
 """
 import argparse
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import threading
 import time
 
@@ -42,7 +54,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=64, help="1080p pairs per step per GPU")
+    ap.add_argument("--batch", type=int, default=256, help="1080p pairs per step per GPU (4 engine batches)")
     ap.add_argument("--slots", type=int, default=64, help="pairs per engine batch (level-major schedule)")
     ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic pairs cycled through")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -91,12 +103,141 @@ def cpu_baseline(pairs):
     dt = time.perf_counter() - t0
     return {"value": njobs / dt, "unit": "pairs/s", "cores": threads, "kind": "port",
             "single_thread_pairs_per_s": round(1.0 / one, 3),
+            "host_cores": cores,
+            "extrapolated_all_host_cores_pairs_per_s": round(njobs / dt / threads * cores, 1),
+            "extrapolation_note": "measured rate per thread x host cores: a one-GPU lease of this pool is granted 16 "
+                                  "of the host's cores, so the all-core figure is an extrapolation, not a measurement",
             "sample": "%d x 1920x1080 synthetic pairs pulled from one queue by %d threads (of %d host cores), %.1f s wall"
                       % (njobs, threads, cores, dt)}, out
 
 
+QUEUE_BIN = os.path.join(ROOT, "tidal-wave_amd", "host", "build", "bench_queue")
+
+
+def write_pgm(path, img):
+    with open(path, "wb") as f:
+        f.write(b"P5\n%d %d\n255\n" % (img.shape[1], img.shape[0]))
+        f.write(np.ascontiguousarray(img).tobytes())
+
+
+def queue_sharded(host_pairs, devices, pairs, per_device=1):
+    """BASELINE config 4's shape: `pairs` in-memory 1080p pairs through ONE twhost::Manager queue with one consumer
+    per device (tools/bench_queue.cpp — a child process: it creates its own engines).  Returns its JSON."""
+    if not os.path.exists(QUEUE_BIN):
+        return {"error": "tidal-wave_amd/host/build/bench_queue is not built"}
+    tmp = tempfile.mkdtemp(prefix="twq_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        for i, (a, b) in enumerate(host_pairs):
+            write_pgm(os.path.join(tmp, "pair_%d_a.pgm" % i), a)
+            write_pgm(os.path.join(tmp, "pair_%d_b.pgm" % i), b)
+        r = subprocess.run([QUEUE_BIN, "--pgm-dir", tmp, "--pairs", str(pairs), "--devices", str(devices),
+                            "--per-device", str(per_device), "--batch", "64", "--warmup-batches", "2"],
+                           capture_output=True, text=True, timeout=900)
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode != 0 or not lines:
+            return {"error": "bench_queue rc %d: %s" % (r.returncode, (r.stderr or r.stdout)[-300:])}
+        out = json.loads(lines[-1])
+        out["note"] = ("one process, one manager queue, %d consumer(s); page-locked in-memory pairs, uploads included; "
+                       "tools/bench_queue.cpp" % out.get("consumers", 0))
+        return out
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def config3_host_pinned(twflow, eng, host_pairs, slots, total=256):
+    """BASELINE configs[2]: `total` 1080p pairs from page-locked host buffers on one GPU; the upload of batch j+1
+    runs on the engine's copy stream under the kernels of batch j; only the hits come back.  Wall clock."""
+    pinned = []
+    for a, b in host_pairs:
+        pa, pb = eng.host_array((H, W)), eng.host_array((H, W))
+        pa[:] = a
+        pb[:] = b
+        pinned.append((pa, pb))
+    nb = max(1, total // slots)
+
+    def submit_batch(k):
+        return [eng.submit(*pinned[(k * slots + j) % len(pinned)]) for j in range(slots)]
+
+    def drain(tk):
+        return sum(eng.wait_count(t)[0] for t in tk)
+
+    drain(submit_batch(0))  # warm-up: the batch contexts' device image regions
+    t0 = time.perf_counter()
+    inflight = [submit_batch(0)] + ([submit_batch(1)] if nb > 1 else [])
+    hits = 0
+    for k in range(2, nb + 2):
+        hits += drain(inflight.pop(0))
+        if k < nb:
+            inflight.append(submit_batch(k))
+    dt = time.perf_counter() - t0
+    n = slots * nb
+    return {"pairs_per_s": round(n / dt, 1), "pairs": n, "ms_per_pair": round(dt / n * 1e3, 4),
+            "h2d_MB_per_pair": round(2 * W * H / 1e6, 2), "flagged_vectors": hits,
+            "note": "page-locked caller buffers (tw_host_alloc), H2D on the copy stream overlapped with the previous "
+                    "batch's kernels, D2H = hit records only; wall clock over %d engine batches of %d" % (nb, slots)}
+
+
+def config5_4k(twflow, synth, batch=8, steps=2):
+    """BASELINE configs[4] on ONE GPU: 3840x2160, pyrLevels 5, winSize 50, iters 5; pairs resident in HBM."""
+    W5, H5 = 3840, 2160
+    kw = dict(pyrLevels=5, winSize=50, pyrIterations=5)
+    with twflow.Engine(0 if "LOCAL_RANK" not in os.environ else int(os.environ["LOCAL_RANK"]),
+                       twflow.default_params(**kw), slots=batch) as e:
+        a, b = synth.make_pair(1, H5, W5)
+        da, db = e.upload(a), e.upload(b)
+
+        def step():
+            tickets = [e.submit_dev(da, db, W5, H5, W5, SPAN, THRESHOLD) for _ in range(batch)]
+            return sum(e.wait_count(t)[0] for t in tickets)
+
+        step()
+        t0 = time.perf_counter()
+        flagged = 0
+        for _ in range(steps):
+            flagged += step()
+        dt = time.perf_counter() - t0
+        per_pair = e.algorithmic_bytes_pair(W5, H5, SPAN)
+        v = batch * steps / dt
+        return {"pairs_per_s": round(v, 2), "pairs": batch * steps, "ms_per_pair": round(1e3 / v, 3),
+                "algorithmic_MB_per_pair": round(per_pair / 1e6, 1), "frac_of_8TBps": round(v * per_pair / 8e12, 4),
+                "levels": e.num_levels(W5, H5) + 1, "flagged_vectors": flagged,
+                "note": "3840x2160, pyrLevels 5, winSize 50, iters 5, one GPU, one distinct synthetic pair resident in HBM"}
+
+
+def queue_mode(args):
+    """`python bench.py --gpus N` without torchrun: the whole job is the queue-sharded driver on N devices."""
+    import synth
+    host_pairs = [synth.make_pair(i, H, W) for i in range(args.distinct)]
+    per_gpu = args.batch
+    out = queue_sharded(host_pairs, args.gpus, per_gpu * args.gpus)
+    if "error" in out:
+        raise SystemExit("queue-sharded run failed: " + out["error"])
+    bytes_pair = 991771776.0  # SURVEY.md 8(d): 1080p, default parameters (tw_algorithmic_bytes_pair)
+    n = out["devices"]
+    line = {
+        "metric": "image-pairs/sec @1080p Farneback (default params), 1/2/4/8 MI355X",
+        "value": out["pairs_per_s"], "unit": "pairs/s", "n_gpus": n, "steps": 1, "warmup": 2,
+        "ms_per_step": round(out["seconds"] * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%d x 1920x1080 u8 gray pairs (%d per GPU) from page-locked host memory through one "
+                               "manager queue with one consumer per GPU (BASELINE config 4's shape), default params, "
+                               "span 10, threshold 5; uploads inside the timed region" % (out["pairs"], per_gpu),
+                   "parallelism": "one process, %d consumers on one request queue, no collective" % out["consumers"]},
+        "pair_roofline": {"algorithmic_bytes_per_pair": bytes_pair,
+                          "frac_of_8TBps": round(bytes_pair * out["pairs_per_s"] / n / 1e9 / HBM_PEAK_GBS, 4)},
+        "queue_sharded": out, "roofline": None, "cpu_baseline": None,
+    }
+    print(json.dumps(line), flush=True)
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return queue_mode(args)
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%s: launch one rank per GPU (torch.distributed.run "
+                         "--nproc-per-node %d), or run without torchrun for the queue-sharded driver"
+                         % (args.gpus, os.environ["WORLD_SIZE"], args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -140,10 +281,10 @@ def main():
 
     flagged = [0]
 
-    def submit_step():
-        # submit the whole batch (the engine launches every `slots` pairs, level-major)
+    def submit_engine_batch(n):
+        # one engine batch (the engine launches every `slots` pairs, level-major)
         tickets = []
-        for j in range(args.batch):
+        for j in range(n):
             da, db = dev_pairs[j % len(dev_pairs)]
             tickets.append(eng.submit_dev(da, db, W, H, W, SPAN, THRESHOLD))
         return tickets
@@ -153,18 +294,25 @@ def main():
             n, _ = eng.wait_count(t)
             flagged[0] += n
 
+    def run_pairs(total):
+        # steady state of a service: the next engine batch is handed over while the previous ones compute (the engine
+        # keeps up to three batches outstanding), so the GPU does not idle during the host's submit calls
+        inflight = []
+        left = total
+        while left > 0:
+            n = min(args.slots, left)
+            inflight.append(submit_engine_batch(n))
+            left -= n
+            if len(inflight) > 2:
+                collect(inflight.pop(0))
+        for t in inflight:
+            collect(t)
+
     def step():
-        collect(submit_step())
+        run_pairs(args.batch)
 
     def run_steps(k):
-        # steady state of a service: the next batch is handed over while the previous one computes (the engine keeps
-        # up to three batches outstanding), so the GPU does not idle during the host's submit calls
-        prev = submit_step()
-        for _ in range(k - 1):
-            cur = submit_step()
-            collect(prev)
-            prev = cur
-        collect(prev)
+        run_pairs(args.batch * k)  # K steps back to back: no drain between steps
 
     # single-pair latency (configs[1]) and a result check before timing
     res0 = eng.diff(host_pairs[0][0], host_pairs[0][1], SPAN, THRESHOLD)
@@ -230,6 +378,7 @@ def main():
     if rank == 0:
         value = pairs_total / elapsed
         bytes_pair = eng.algorithmic_bytes_pair(W, H, SPAN)
+        min_pair = eng.min_traffic_bytes_pair(W, H, SPAN)
         # measured device copy rate of this GPU in this run (report it beside the 8 TB/s nominal peak):
         # 1 GiB torch copy, read + write counted, outside the timed region
         copy_gbs = None
@@ -274,6 +423,10 @@ def main():
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                     "traffic": tr.get("bytes_per_launch") if isinstance(tr, dict) else tr,
                     "traffic_pairs_per_launch": tr.get("pairs_per_launch") if isinstance(tr, dict) else None,
+                    "traffic_source": "profiles/traffic_latest.json (static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                      "passes of an earlier run of this command, not a live counter)",
+                    "bytes_model": "what the kernel as built must move per launch (blur+solve: 80 B/px for a launch "
+                                   "fused with the matrix refresh, 28 B/px for the last one; polyexp 24 B/px)",
                     "algorithmic_bytes_per_launch": bytes_total / n,
                     "avg_launch_us": round(ms / n * 1e3, 2), "launches": n,
                     "pairs_per_launch": round(per_pair_launches * pairs_mine / n, 2), "level_chunk": chunk,
@@ -296,6 +449,11 @@ def main():
             "pair_roofline": {"algorithmic_bytes_per_pair": bytes_pair,
                               "achieved_GBps_per_gpu": round(bytes_pair * value / world / 1e9, 1),
                               "frac_of_8TBps": round(bytes_pair * value / world / 1e9 / HBM_PEAK_GBS, 4),
+                              "min_traffic_bytes_per_pair": min_pair,
+                              "frac_of_8TBps_min_traffic": round(min_pair * value / world / 1e9 / HBM_PEAK_GBS, 4),
+                              "note": "algorithmic = SURVEY.md 8(d) model of the reference's stages (991.8 MB); "
+                                      "min_traffic = what the fused kernels as built must move (flows that stay in "
+                                      "registers are not stored)",
                               "frac_of_measured_copy": round(bytes_pair * value / world / 1e9 / copy_gbs, 4)
                               if copy_gbs else None},
             "kernel_breakdown": breakdown,
@@ -307,6 +465,15 @@ def main():
             "roofline_polyexp": roof(twflow.K_POLYEXP),
             "flagged_vectors": flagged_total,
         }
+        if world == 1 and not args.no_extras:
+            # the other BASELINE configs, outside the timed region (never `value`)
+            for key, fn in (("config3_host_pinned", lambda: config3_host_pinned(twflow, eng, host_pairs, args.slots)),
+                            ("config5_4k", lambda: config5_4k(twflow, synth)),
+                            ("queue_sharded", lambda: queue_sharded(host_pairs, 1, 2048))):
+                try:
+                    line[key] = fn()
+                except Exception as ex:  # an extra must never cost the headline line
+                    line[key] = {"error": "%s: %s" % (type(ex).__name__, ex)}
         if world == 1 and not args.no_cpu_baseline:
             cb, cpu_out = cpu_baseline(host_pairs)
             line["cpu_baseline"] = cb
