@@ -79,3 +79,32 @@ def test_oracle_linearity_in_flags_and_sizes(oracle):
                    dict(pyrScale=0.8, pyrLevels=2)]:
             fx, fy = oracle.farneback(a, b, oracle.default_params(**kw))
             assert np.isfinite(fx).all() and np.isfinite(fy).all()
+
+
+def test_negative_control_rounding_gray_decode_matches_no_golden_vector(oracle, golden):
+    """The fixture decode (libpng 1.5's truncating rgb_to_gray, tests/golden/make_fixtures.py) was chosen because it
+    makes the reference's 24 vectors exact.  The control that justifies it, kept as a test rather than prose: the
+    same PNGs decoded with the ROUNDING formula (libpng 1.6 / PIL convert('L'): (19595 R + 38470 G + 7471 B +
+    32768) >> 16) differ from the fixture decode in a few dozen pixels by one grey level — and with that decode
+    not one of the 24 golden vectors (test/index.coffee:67-91) is reproduced bit for bit."""
+    import os
+    Image = pytest.importorskip("PIL.Image")
+    tree = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tree")
+    imgs = {}
+    for rev in ("expected", "revision2"):
+        rgb = np.asarray(Image.open(os.path.join(tree, rev, "scenario2", "capture2.png")).convert("RGB"), dtype=np.int64)
+        r, g, b = rgb[..., 0], rgb[..., 1], rgb[..., 2]
+        imgs[rev] = ((19595 * r + 38470 * g + 7471 * b + 32768) >> 16).astype(np.uint8)
+        assert np.array_equal(imgs[rev], np.asarray(Image.fromarray(rgb.astype(np.uint8)).convert("L")))  # PIL's own 'L'
+    c = golden["revision2_capture2"]
+    ndiff = int((imgs["expected"] != c["expect_img"]).sum()) + int((imgs["revision2"] != c["target_img"]).sum())
+    assert 0 < ndiff < 1000
+    assert int(np.abs(imgs["expected"].astype(int) - c["expect_img"].astype(int)).max()) == 1
+    fx, fy = oracle.farneback(imgs["expected"], imgs["revision2"])
+    got = {(x, y): (dx, dy) for x, y, dx, dy in oracle.span_scan(fx, fy, c["span"], float(c["threshold"]))}
+    want = {(d["x"], d["y"]): (d["dx"], d["dy"]) for d in c["vector"]}
+    exact = sum(1 for k, v in want.items() if got.get(k) == v)
+    assert exact == 0, "%d of 24 golden vectors are exact with the rounding decode" % exact
+    # it is a near miss, not a different algorithm: the same grid points are flagged, values agree to ~1e-2
+    common = [k for k in want if k in got]
+    assert len(common) >= 20

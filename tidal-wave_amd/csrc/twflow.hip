@@ -303,6 +303,7 @@ struct tw_engine {
     int scan_fused = 0;    // TW_OPT_SCAN_FUSED_FINAL
     int pyr_generic = 0;   // TW_PYR_GENERIC=1: always the generic pyramid kernel, 2: tw_pyr_level_lds for every level (A/B)
     int blur_variant = 4;  // 4: tw_blur_solve4 (default); 8: tw_blur_solve8 (packed f32) — TW_BLUR_VARIANT
+    int blur_small = -1;   // TW_BLUR_SMALL: force the small-grid tile choice of the 31-tap blur (-1: by grid size)
     int poly_variant = 1;  // 1: tw_polyexp_pk<N,8> (packed f32, default); 2: tw_polyexp_pk<N,16>; 0: tw_polyexp (scalar f32) — TW_POLY_VARIANT
     std::string err;
     // device workspace, shared by all batches (execution is ordered on one stream)
@@ -310,6 +311,13 @@ struct tw_engine {
     float *I = nullptr, *R = nullptr, *M[2] = {nullptr, nullptr};
     std::vector<float*> flow;            // per level, cap (levels>=1) or chunk0 (level 0) pairs x 2 planes
     std::vector<size_t> flow_cap;
+    // single-pair latency schedule (BASELINE config 2): a batch of one pair runs the pyramid + polynomial expansion of
+    // every level on stream2 (they depend only on the images) while the main stream walks the flow chain coarse to
+    // fine; needs every level's I and R at once (TW_LATENCY_STREAMS=0: everything on one stream)
+    int lat_streams = 1;
+    float *lat_I = nullptr, *lat_R = nullptr;
+    size_t lat_cap = 0;  // floats in lat_I (lat_R holds 5x)
+    std::vector<hipEvent_t> lat_ev;
     hipStream_t copy_stream = nullptr;  // host -> device image uploads, overlapped with the compute stream
     const uint8_t** d_ptrs = nullptr;  // [2*cap]
     int* d_count = nullptr;            // [cap]
@@ -516,6 +524,9 @@ tw_status reserve_workspace(tw_engine* e, const Plan* pl, int span, bool need_im
     (void)need_img;  // image regions belong to the batch contexts (submit_common)
     const size_t G = span > 0 ? (size_t)tw_grid_capacity(pl->w0, pl->h0, span) : 0;
     if (G * e->cap > e->d_grid_cap) grow = true;
+    size_t need_lat = 0;
+    for (const LevelPlan& L : pl->lv) need_lat += (size_t)L.ps * 2;
+    if (e->lat_streams && (need_lat > e->lat_cap || e->lat_ev.size() < pl->lv.size())) grow = true;
     if (!grow) return TW_OK;
     TW_HIP(e, hipStreamSynchronize(e->stream));
     TW_HIP(e, hipStreamSynchronize(e->stream2));
@@ -531,6 +542,20 @@ tw_status reserve_workspace(tw_engine* e, const Plan* pl, int span, bool need_im
         TW_HIP(e, hipMalloc((void**)&e->M[0], need / 2 * 5 * 4 + 256));
         TW_HIP(e, hipMalloc((void**)&e->M[1], need / 2 * 5 * 4 + 256));
         e->ws_elems = need;
+    }
+    if (e->lat_streams && need_lat > e->lat_cap) {
+        if (e->lat_I) (void)hipFree(e->lat_I);
+        if (e->lat_R) (void)hipFree(e->lat_R);
+        e->lat_I = e->lat_R = nullptr;
+        e->lat_cap = 0;
+        TW_HIP(e, hipMalloc((void**)&e->lat_I, need_lat * 4 + 256));
+        TW_HIP(e, hipMalloc((void**)&e->lat_R, need_lat * 5 * 4 + 256));
+        e->lat_cap = need_lat;
+    }
+    while (e->lat_streams && e->lat_ev.size() < pl->lv.size()) {
+        hipEvent_t ev = nullptr;
+        TW_HIP(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        e->lat_ev.push_back(ev);
     }
     if (e->box && need / 2 * 5 > e->Vd_cap) {
         if (e->Vd) (void)hipFree(e->Vd);
@@ -793,6 +818,27 @@ void launch_blur(tw_engine* e, hipStream_t st, int w, int h, int ld, long long p
         if (wide) hipLaunchKernelGGL((tw_blur_solve8<15, 256, 16, 8, true, true>), dim3((w + 223) / 224, gy, npairs), dim3(256), 0, st, a);
         else hipLaunchKernelGGL((tw_blur_solve8<15, 128, 16, 8, true, true>), dim3((w + 95) / 96, gy, npairs), dim3(128), 0, st, a);
     } else if (e->win_m == 15) {
+        // Small grids (a single pair, the coarse levels): a level that would launch fewer than two workgroups per
+        // CU takes smaller tiles, so that more CUs share it and each workgroup's serial V -> H -> S chain is shorter
+        // (BASELINE config 2, single-pair latency).  Batched launches always have enough tiles and keep the big ones.
+        auto nwg = [&](int tw, int th) { return (long long)((w + tw - 1) / tw) * ((h + th - 1) / th) * npairs; };
+        const long long enough = 512;
+        int small = 0;  // 0: 224x8 / 96x8 tiles as below, 1: 96x8 (128 threads), 2: 96x4 (128 threads), 3: 32x4 (64 threads)
+        if (e->blur_small >= 0) small = e->blur_small;
+        else if (wide && nwg(224, 8) >= enough) small = 0;
+        else if (nwg(96, 8) >= enough) small = wide ? 1 : 0;
+        else if (nwg(96, 4) >= enough) small = 2;
+        else small = 3;
+        if (small) {
+            const int tw = small == 3 ? 32 : 96, th = small == 1 ? 8 : 4;
+            a.xsh = ((w + 16 + tw - 1) / tw == (w + tw - 1) / tw) ? 16 : 0;
+            a.rot = a.xsh;
+            const dim3 grid((w + a.xsh + tw - 1) / tw, (h + th - 1) / th, npairs);
+            if (small == 1) hipLaunchKernelGGL((tw_blur_solve4<15, 128, 16, 8, true>), grid, dim3(128), 0, st, a);
+            else if (small == 2) hipLaunchKernelGGL((tw_blur_solve4<15, 128, 16, 4, true>), grid, dim3(128), 0, st, a);
+            else hipLaunchKernelGGL((tw_blur_solve4<15, 64, 16, 4, true>), grid, dim3(64), 0, st, a);
+            return;
+        }
         // shift the tile grid 16 px left when that costs no extra tile column (see the kernel)
         const int tw = wide ? 224 : 96;
         a.xsh = ((w + 16 + tw - 1) / tw == (w + tw - 1) / tw) ? 16 : 0;
@@ -903,6 +949,25 @@ tw_status flush_ctx(tw_engine* e, Ctx& c)
     }
     size_t ws_lane = 0;
     for (const LevelPlan& L : pl->lv) ws_lane = std::max(ws_lane, (size_t)L.ps * 2 * L.chunk);
+    // one pair: image-only work (pyramid, polynomial expansion) of all levels on the second stream
+    const bool lat = n == 1 && nlanes == 1 && e->lat_streams && e->lat_I;
+    std::vector<size_t> lat_off(pl->lv.size(), 0);
+    if (lat) {
+        size_t off = 0;
+        for (size_t k = 0; k < pl->lv.size(); k++) {
+            lat_off[k] = off;
+            off += (size_t)pl->lv[k].ps * 2;
+        }
+        TW_HIP(e, hipEventRecord(e->ev_fork, st));  // pointer table + uploads + the previous batch's use of lat_I / lat_R
+        TW_HIP(e, hipStreamWaitEvent(e->stream2, e->ev_fork, 0));
+        for (int k = pl->levels; k >= 0; k--) {
+            const LevelPlan& L = pl->lv[k];
+            launch_pyr(e, e->stream2, pl, k, e->d_ptrs, stride, e->lat_I + lat_off[k], 2);
+            if ((r = launch_polyexp(e, e->stream2, L.w, L.h, L.ld, L.ps, e->lat_I + lat_off[k], e->lat_R + 5 * lat_off[k], 2, k)))
+                return r;
+            TW_HIP(e, hipEventRecord(e->lat_ev[k], e->stream2));
+        }
+    }
     for (int lane = 0; lane < nlanes; lane++) {
         hipStream_t ls = lane == 0 ? st : e->stream2;
         const int lo = (int)((long long)n * lane / nlanes), hi = (int)((long long)n * (lane + 1) / nlanes);
@@ -918,8 +983,13 @@ tw_status flush_ctx(tw_engine* e, Ctx& c)
                 float* flow_cur = e->flow[k] + (k == 0 ? (size_t)lane * L.chunk * 2 * L.ps : (size_t)j0 * 2 * L.ps);
                 const float* flow_prev =
                     k < pl->levels ? e->flow[k + 1] + (size_t)j0 * 2 * pl->lv[k + 1].ps : nullptr;
-                launch_pyr(e, ls, pl, k, e->d_ptrs + 2 * j0, stride, I, 2 * nc);
-                if ((r = launch_polyexp(e, ls, L.w, L.h, L.ld, L.ps, I, R, 2 * nc, k))) return r;
+                if (lat) {
+                    R = e->lat_R + 5 * lat_off[k];
+                    TW_HIP(e, hipStreamWaitEvent(ls, e->lat_ev[k], 0));
+                } else {
+                    launch_pyr(e, ls, pl, k, e->d_ptrs + 2 * j0, stride, I, 2 * nc);
+                    if ((r = launch_polyexp(e, ls, L.w, L.h, L.ld, L.ps, I, R, 2 * nc, k))) return r;
+                }
                 launch_update(e, ls, pl, k, R, flow_cur, flow_prev, M0, nc);
                 // scan-fused final iteration (option TW_OPT_SCAN_FUSED_FINAL): nothing but the span grid of the last
                 // level-0 flow is read afterwards, so the last window average + solve runs at the grid points only
@@ -1207,10 +1277,16 @@ tw_status tw_engine_create(int device, const tw_params* params, int slots, tw_en
     if (const char* ev = getenv("TW_BLUR_VARIANT")) e->blur_variant = atoi(ev);
     if (const char* ev = getenv("TW_PYR_GENERIC")) e->pyr_generic = atoi(ev);
     if (const char* ev = getenv("TW_POLY_VARIANT")) e->poly_variant = atoi(ev);
+    if (const char* ev = getenv("TW_BLUR_SMALL")) e->blur_small = atoi(ev);
     if (const char* ev = getenv("TW_UPD_NY")) e->upd_ny = atoi(ev) == 1 ? 1 : 2;
     if (const char* ev = getenv("TW_LANES")) e->lanes = std::min(2, std::max(1, atoi(ev)));
-    bool ok = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) == hipSuccess &&
-              hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking) == hipSuccess &&
+    if (const char* ev = getenv("TW_LATENCY_STREAMS")) e->lat_streams = atoi(ev) ? 1 : 0;
+    // the main stream carries the dependent flow chain: highest priority, so that its small launches are not queued
+    // behind the second stream's image-only work
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    bool ok = hipStreamCreateWithPriority(&e->stream, hipStreamNonBlocking, prio_hi) == hipSuccess &&
+              hipStreamCreateWithPriority(&e->stream2, hipStreamNonBlocking, e->lanes > 1 ? prio_hi : prio_lo) == hipSuccess &&
               hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking) == hipSuccess &&
               hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) == hipSuccess &&
@@ -1248,6 +1324,9 @@ void tw_engine_destroy(tw_engine* e)
     if (e->d_count) (void)hipFree(e->d_count);
     if (e->d_grid) (void)hipFree(e->d_grid);
     if (e->Vd) (void)hipFree(e->Vd);
+    if (e->lat_I) (void)hipFree(e->lat_I);
+    if (e->lat_R) (void)hipFree(e->lat_R);
+    for (hipEvent_t ev : e->lat_ev) (void)hipEventDestroy(ev);
     for (Ctx& c : e->ctx) {
         if (c.h_img) (void)hipHostFree(c.h_img);
         if (c.d_img) (void)hipFree(c.d_img);
