@@ -303,6 +303,7 @@ struct tw_engine {
     int scan_fused = 0;    // TW_OPT_SCAN_FUSED_FINAL
     int pyr_generic = 0;   // TW_PYR_GENERIC=1: always the generic pyramid kernel, 2: tw_pyr_level_lds for every level (A/B)
     int blur_variant = 4;  // 4: tw_blur_solve4 (default); 8: tw_blur_solve8 (packed f32) — TW_BLUR_VARIANT
+    int pp_waves = 512;    // TW_PP_WAVES: below this many waves of 96x8 tiles a level takes the plane-parallel kernel
     int blur_small = -1;   // TW_BLUR_SMALL: force the small-grid tile choice of the 31-tap blur (-1: by grid size)
     int poly_variant = 1;  // 1: tw_polyexp_pk<N,8> (packed f32, default); 2: tw_polyexp_pk<N,16>; 0: tw_polyexp (scalar f32) — TW_POLY_VARIANT
     std::string err;
@@ -315,6 +316,7 @@ struct tw_engine {
     // every level on stream2 (they depend only on the images) while the main stream walks the flow chain coarse to
     // fine; needs every level's I and R at once (TW_LATENCY_STREAMS=0: everything on one stream)
     int lat_streams = 1;
+    long long lat_min_px = 100000;  // TW_LATENCY_MIN_PX
     float *lat_I = nullptr, *lat_R = nullptr;
     size_t lat_cap = 0;  // floats in lat_I (lat_R holds 5x)
     std::vector<hipEvent_t> lat_ev;
@@ -554,7 +556,7 @@ tw_status reserve_workspace(tw_engine* e, const Plan* pl, int span, bool need_im
     }
     while (e->lat_streams && e->lat_ev.size() < pl->lv.size()) {
         hipEvent_t ev = nullptr;
-        TW_HIP(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        TW_HIP(e, hipEventCreateWithFlags(&ev, getenv("TW_LAT_EVTIMING") ? hipEventDefault : hipEventDisableTiming));
         e->lat_ev.push_back(ev);
     }
     if (e->box && need / 2 * 5 > e->Vd_cap) {
@@ -822,21 +824,22 @@ void launch_blur(tw_engine* e, hipStream_t st, int w, int h, int ld, long long p
         // CU takes smaller tiles, so that more CUs share it and each workgroup's serial V -> H -> S chain is shorter
         // (BASELINE config 2, single-pair latency).  Batched launches always have enough tiles and keep the big ones.
         auto nwg = [&](int tw, int th) { return (long long)((w + tw - 1) / tw) * ((h + th - 1) / th) * npairs; };
-        const long long enough = 512;
         int small = 0;  // 0: 224x8 / 96x8 tiles as below, 1: 96x8 (128 threads), 2: 96x4 (128 threads), 3: 32x4 (64 threads)
+                        // 4: plane-parallel 32x8 (320 threads), 5: plane-parallel 96x8 (640 threads)
         if (e->blur_small >= 0) small = e->blur_small;
-        else if (wide && nwg(224, 8) >= enough) small = 0;
-        else if (nwg(96, 8) >= enough) small = wide ? 1 : 0;
-        else if (nwg(96, 4) >= enough) small = 2;
-        else small = 3;
+        else if (wide && nwg(224, 8) >= 1024) small = 0;   // four 256-thread workgroups per CU: throughput regime
+        else if (nwg(96, 8) * 2 >= e->pp_waves) small = wide ? 1 : 0;  // enough 2-wave workgroups to keep every SIMD busy
+        else small = 4;  // otherwise many small plane-parallel workgroups (5 waves per 32x8 pixels)
         if (small) {
-            const int tw = small == 3 ? 32 : 96, th = small == 1 ? 8 : 4;
+            const int tw = (small == 3 || small == 4) ? 32 : 96, th = (small == 2 || small == 3) ? 4 : 8;
             a.xsh = ((w + 16 + tw - 1) / tw == (w + tw - 1) / tw) ? 16 : 0;
             a.rot = a.xsh;
             const dim3 grid((w + a.xsh + tw - 1) / tw, (h + th - 1) / th, npairs);
             if (small == 1) hipLaunchKernelGGL((tw_blur_solve4<15, 128, 16, 8, true>), grid, dim3(128), 0, st, a);
             else if (small == 2) hipLaunchKernelGGL((tw_blur_solve4<15, 128, 16, 4, true>), grid, dim3(128), 0, st, a);
-            else hipLaunchKernelGGL((tw_blur_solve4<15, 64, 16, 4, true>), grid, dim3(64), 0, st, a);
+            else if (small == 3) hipLaunchKernelGGL((tw_blur_solve4<15, 64, 16, 4, true>), grid, dim3(64), 0, st, a);
+            else if (small == 4) hipLaunchKernelGGL((tw_blur_solve_pp<15, 64, 16, 8>), grid, dim3(320), 0, st, a);
+            else hipLaunchKernelGGL((tw_blur_solve_pp<15, 128, 16, 8>), grid, dim3(640), 0, st, a);
             return;
         }
         // shift the tile grid 16 px left when that costs no extra tile column (see the kernel)
@@ -950,7 +953,9 @@ tw_status flush_ctx(tw_engine* e, Ctx& c)
     size_t ws_lane = 0;
     for (const LevelPlan& L : pl->lv) ws_lane = std::max(ws_lane, (size_t)L.ps * 2 * L.chunk);
     // one pair: image-only work (pyramid, polynomial expansion) of all levels on the second stream
-    const bool lat = n == 1 && nlanes == 1 && e->lat_streams && e->lat_I;
+    // (only worth its cross-stream hand-offs when the image-only work is tens of microseconds: >= 0.1 Mpixel)
+    const bool lat = n == 1 && nlanes == 1 && e->lat_streams && e->lat_I && pl->levels >= 1 &&
+                     (long long)c.w * c.h >= e->lat_min_px;
     std::vector<size_t> lat_off(pl->lv.size(), 0);
     if (lat) {
         size_t off = 0;
@@ -960,12 +965,15 @@ tw_status flush_ctx(tw_engine* e, Ctx& c)
         }
         TW_HIP(e, hipEventRecord(e->ev_fork, st));  // pointer table + uploads + the previous batch's use of lat_I / lat_R
         TW_HIP(e, hipStreamWaitEvent(e->stream2, e->ev_fork, 0));
+        // the coarsest level's images are needed at once: they stay on the main stream (no hand-off to wait for);
+        // the finer levels' are ready long before the flow chain reaches them
         for (int k = pl->levels; k >= 0; k--) {
             const LevelPlan& L = pl->lv[k];
-            launch_pyr(e, e->stream2, pl, k, e->d_ptrs, stride, e->lat_I + lat_off[k], 2);
-            if ((r = launch_polyexp(e, e->stream2, L.w, L.h, L.ld, L.ps, e->lat_I + lat_off[k], e->lat_R + 5 * lat_off[k], 2, k)))
+            hipStream_t ws = k == pl->levels ? st : e->stream2;
+            launch_pyr(e, ws, pl, k, e->d_ptrs, stride, e->lat_I + lat_off[k], 2);
+            if ((r = launch_polyexp(e, ws, L.w, L.h, L.ld, L.ps, e->lat_I + lat_off[k], e->lat_R + 5 * lat_off[k], 2, k)))
                 return r;
-            TW_HIP(e, hipEventRecord(e->lat_ev[k], e->stream2));
+            if (k < pl->levels) TW_HIP(e, hipEventRecord(e->lat_ev[k], e->stream2));
         }
     }
     for (int lane = 0; lane < nlanes; lane++) {
@@ -985,7 +993,7 @@ tw_status flush_ctx(tw_engine* e, Ctx& c)
                     k < pl->levels ? e->flow[k + 1] + (size_t)j0 * 2 * pl->lv[k + 1].ps : nullptr;
                 if (lat) {
                     R = e->lat_R + 5 * lat_off[k];
-                    TW_HIP(e, hipStreamWaitEvent(ls, e->lat_ev[k], 0));
+                    if (k < pl->levels) TW_HIP(e, hipStreamWaitEvent(ls, e->lat_ev[k], 0));
                 } else {
                     launch_pyr(e, ls, pl, k, e->d_ptrs + 2 * j0, stride, I, 2 * nc);
                     if ((r = launch_polyexp(e, ls, L.w, L.h, L.ld, L.ps, I, R, 2 * nc, k))) return r;
@@ -1278,9 +1286,11 @@ tw_status tw_engine_create(int device, const tw_params* params, int slots, tw_en
     if (const char* ev = getenv("TW_PYR_GENERIC")) e->pyr_generic = atoi(ev);
     if (const char* ev = getenv("TW_POLY_VARIANT")) e->poly_variant = atoi(ev);
     if (const char* ev = getenv("TW_BLUR_SMALL")) e->blur_small = atoi(ev);
+    if (const char* ev = getenv("TW_PP_WAVES")) e->pp_waves = atoi(ev);
     if (const char* ev = getenv("TW_UPD_NY")) e->upd_ny = atoi(ev) == 1 ? 1 : 2;
     if (const char* ev = getenv("TW_LANES")) e->lanes = std::min(2, std::max(1, atoi(ev)));
     if (const char* ev = getenv("TW_LATENCY_STREAMS")) e->lat_streams = atoi(ev) ? 1 : 0;
+    if (const char* ev = getenv("TW_LATENCY_MIN_PX")) e->lat_min_px = atoll(ev);
     // the main stream carries the dependent flow chain: highest priority, so that its small launches are not queued
     // behind the second stream's image-only work
     int prio_lo = 0, prio_hi = 0;

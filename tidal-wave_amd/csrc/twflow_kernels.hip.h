@@ -407,34 +407,52 @@ __global__ __launch_bounds__(256) void tw_pyr_taps(PyrTapsArgs aa)
     const int pd = aa.pd;
 
     // ---- stage the u8 region ----
+    // A wave takes the rows wv, wv+4, ...; a lane the dwords lane, lane+64 of a row.  Eight rows x two dwords are
+    // loaded before anything is stored, so a tile pays two or three memory round trips instead of one per four
+    // rows and per 64 dwords (the coarse levels of a single pair are latency-bound: BASELINE config 2).
     {
         const __amdgpu_buffer_rsrc_t rs = make_rsrc(src);
         const int stride = (int)a.stride;
-        for (int dw = lane; dw < ndw; dw += 64) {
-            const int c0 = xlo_a + 4 * dw;
-            const bool fast = aa.aligned4 && c0 >= 0 && c0 + 3 < a.w0;
-            int cc[4];
+        constexpr int NB = 8;
+        for (int dwb = lane; dwb < ndw; dwb += 128) {
+            int c0[2], cc[2][4];
+            bool fast[2], live[2];
 #pragma unroll
-            for (int u = 0; u < 4; u++) cc[u] = reflect101(c0 + u, a.w0);
-            for (int rb = wv; rb < nrows; rb += 16) {
-                unsigned v[4];
+            for (int d = 0; d < 2; d++) {
+                const int dw = dwb + 64 * d;
+                live[d] = dw < ndw;
+                c0[d] = xlo_a + 4 * dw;
+                fast[d] = aa.aligned4 && c0[d] >= 0 && c0[d] + 3 < a.w0;
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
+                for (int u = 0; u < 4; u++) cc[d][u] = reflect101(c0[d] + u, a.w0);
+            }
+            for (int rb = wv; rb < nrows; rb += 4 * NB) {
+                unsigned v[NB][2];
+#pragma unroll
+                for (int u = 0; u < NB; u++) {
                     const int rr = rb + 4 * u;
                     const int Y = reflect101(ylo + min(rr, nrows - 1), a.h0);
                     const unsigned ro = (unsigned)(Y * stride);
-                    if (fast) {
-                        v[u] = __builtin_amdgcn_raw_buffer_load_b32(rs, (unsigned)c0 + ro, 0, 0);
-                    } else {
-                        const uint8_t* __restrict__ S = src + ro;
-                        v[u] = (unsigned)S[cc[0]] | ((unsigned)S[cc[1]] << 8) | ((unsigned)S[cc[2]] << 16) |
-                               ((unsigned)S[cc[3]] << 24);
+#pragma unroll
+                    for (int d = 0; d < 2; d++) {
+                        v[u][d] = 0;
+                        if (!live[d]) continue;
+                        if (fast[d]) {
+                            v[u][d] = __builtin_amdgcn_raw_buffer_load_b32(rs, (unsigned)c0[d] + ro, 0, 0);
+                        } else {
+                            const uint8_t* __restrict__ S = src + ro;
+                            v[u][d] = (unsigned)S[cc[d][0]] | ((unsigned)S[cc[d][1]] << 8) | ((unsigned)S[cc[d][2]] << 16) |
+                                      ((unsigned)S[cc[d][3]] << 24);
+                        }
                     }
                 }
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
+                for (int u = 0; u < NB; u++) {
                     const int rr = rb + 4 * u;
-                    if (rr < nrows) tile[rr * pd + dw] = v[u];
+                    if (rr < nrows) {
+                        if (live[0]) tile[rr * pd + dwb] = v[u][0];
+                        if (live[1]) tile[rr * pd + dwb + 64] = v[u][1];
+                    }
                 }
             }
         }
@@ -1449,6 +1467,137 @@ __global__ __launch_bounds__(COLS) __attribute__((amdgpu_waves_per_eu(4, 8))) vo
 #pragma unroll
                     for (int cc = 0; cc < 5; cc++) Mout[o + cc * a.ps] = M[cc];
                 }
+            }
+        }
+    }
+}
+
+// -----------------------------------------------------------------------------------------------------
+// tw_blur_solve_pp<MH,COLS,HALO,TH> : the same arithmetic for SMALL grids (one pair, coarse levels), where a launch
+//   is a single round of workgroups and its duration is one workgroup's serial V -> H -> S chain, not throughput.
+//   Plane-parallel: a workgroup has 5 x COLS threads, thread group g = tid / COLS owns plane g of M in the vertical
+//   and in the horizontal pass (a fifth of tw_blur_solve4's chain per wave), all groups share the solve / refresh.
+//   Same LDS layout, same operation order per value; twice the halo overhead at COLS = 64 is irrelevant here.
+// -----------------------------------------------------------------------------------------------------
+template <int MH, int COLS, int HALO, int TH>
+__global__ __launch_bounds__(5 * COLS) void tw_blur_solve_pp(BlurArgs a)
+{
+    constexpr int TW = COLS - 2 * HALO;
+    constexpr int NW = TH + 2 * MH;
+    constexpr int NT = 5 * COLS;
+    __shared__ __attribute__((aligned(16))) float sm[5][TH][COLS];
+    const int tid = threadIdx.x, ch = tid / COLS, ct = tid - ch * COLS;
+    int bx, by, z;
+    xcd_remap(bx, by, z);
+    const int x0 = bx * TW - a.xsh, y0 = by * TH;
+    const WinCoef& c = a.c;
+    const float* __restrict__ Min = a.Min + (long long)z * 5 * a.ps;
+    float* __restrict__ flow = a.flow + (long long)z * 2 * a.fps;
+
+    // ---- V: plane ch, column ct ----
+    {
+        const unsigned xb = (unsigned)clampi(x0 - HALO + ct, 0, a.w - 1) * 4u;
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(Min + (long long)ch * a.ps);
+        float wa[NW];
+#pragma unroll
+        for (int i = 0; i < NW; i++)
+            wa[i] = bload(rs, xb, (unsigned)clampi(y0 - MH + i, 0, a.h - 1) * ((unsigned)a.ld * 4u));
+#pragma unroll
+        for (int r = 0; r < TH; r++) {
+            float s0 = wa[r + MH] * c.k[0];
+#pragma unroll
+            for (int i = 1; i <= MH; i++) s0 += (wa[r + MH + i] + wa[r + MH - i]) * c.k[i];
+            sm[ch][r][ct] = s0;
+            if (r & 1) __builtin_amdgcn_sched_barrier(0);  // two rows in flight
+        }
+    }
+    // the R0 coefficients of the lane's S-phase pixels do not depend on the flow: fetch them under the H pass
+    constexpr int NPX = (TH * TW + NT - 1) / NT;
+    float qpre[NPX][5];
+    if (a.update) {
+        const float* __restrict__ R0p = a.R + (long long)(2 * z) * 5 * a.ps;
+#pragma unroll
+        for (int i = 0; i < NPX; i++) {
+            const int p = min(tid + i * NT, TH * TW - 1);
+            const int r = p / TW, c0 = p - r * TW + a.rot, cx = c0 >= TW ? c0 - TW : c0;
+            const int xc = clampi(x0 + cx, 0, a.w - 1), yc = min(y0 + r, a.h - 1);
+            const long long o = (long long)yc * a.ld + xc;
+#pragma unroll
+            for (int cc = 0; cc < 5; cc++) qpre[i][cc] = R0p[o + cc * a.ps];
+        }
+    }
+    __syncthreads();
+
+    // ---- H: plane ch, 4 pixels per item ----
+    constexpr int GROUPS = TW / 4;
+    constexpr int NITEM = TH * GROUPS;
+    constexpr int ROUNDS = (NITEM + COLS - 1) / COLS;
+    constexpr int WL = 4 + 2 * HALO;
+    f32x4 res[ROUNDS];
+#pragma unroll
+    for (int rd = 0; rd < ROUNDS; rd++) {
+        const int it = ct + rd * COLS;
+        if (it < NITEM) {
+            const int r = it / GROUPS, q = it - r * GROUPS;
+            float v[WL];
+#pragma unroll
+            for (int u = 0; u < WL / 4; u++) {
+                const f32x4 A = *(const f32x4*)&sm[ch][r][4 * q + 4 * u];
+                v[4 * u] = A[0];
+                v[4 * u + 1] = A[1];
+                v[4 * u + 2] = A[2];
+                v[4 * u + 3] = A[3];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int li = HALO + j;
+                float sum = v[li] * c.k[0];
+#pragma unroll
+                for (int i = 1; i <= MH; i++) sum += c.k[i] * (v[li - i] + v[li + i]);
+                res[rd][j] = sum;
+                if (j & 1) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    __syncthreads();  // every window has been read: the interiors may be overwritten
+#pragma unroll
+    for (int rd = 0; rd < ROUNDS; rd++) {
+        const int it = ct + rd * COLS;
+        if (it < NITEM) {
+            const int r = it / GROUPS, q = it - r * GROUPS;
+            *(f32x4*)&sm[ch][r][HALO + 4 * q] = res[rd];
+        }
+    }
+    __syncthreads();
+
+    // ---- S: solve (+ refresh), lane-consecutive pixels over all 5*COLS threads ----
+    float* __restrict__ Mout = a.Mout + (long long)z * 5 * a.ps;
+    const float* __restrict__ R1 = a.R + (long long)(2 * z) * 5 * a.ps + 5 * a.ps;
+#pragma unroll
+    for (int i = 0; i < NPX; i++) {
+        const int p = tid + i * NT;
+        const bool mine = p < TH * TW;
+        const int pc = mine ? p : TH * TW - 1;
+        const int r = pc / TW, c0 = pc - r * TW + a.rot, cx = c0 >= TW ? c0 - TW : c0;
+        const int x = x0 + cx, y = y0 + r;
+        const bool valid = mine && x >= 0 && x < a.w && y < a.h;
+        const int xc = clampi(x, 0, a.w - 1), yc = min(y, a.h - 1);
+        const double g11 = sm[0][r][HALO + cx], g12 = sm[1][r][HALO + cx], g22 = sm[2][r][HALO + cx],
+                     h1 = sm[3][r][HALO + cx], h2 = sm[4][r][HALO + cx];
+        const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
+        const float fxv = (float)((g11 * h2 - g12 * h1) * idet);
+        const float fyv = (float)((g22 * h1 - g12 * h2) * idet);
+        const long long o = (long long)yc * a.ld + xc;
+        if (valid && (!a.update || a.store_flow)) {
+            flow[o] = fxv;
+            flow[o + a.fps] = fyv;
+        }
+        if (a.update) {  // wave-uniform
+            float M[5];
+            update_matrices_core(qpre[i], R1, a.ps, a.ld, a.w, a.h, xc, yc, fxv, fyv, M);
+            if (valid) {
+#pragma unroll
+                for (int cc = 0; cc < 5; cc++) Mout[o + cc * a.ps] = M[cc];
             }
         }
     }
