@@ -304,6 +304,7 @@ struct tw_engine {
     int pyr_generic = 0;   // TW_PYR_GENERIC=1: always the generic pyramid kernel, 2: tw_pyr_level_lds for every level (A/B)
     int blur_variant = 4;  // 4: tw_blur_solve4 (default); 8: tw_blur_solve8 (packed f32) — TW_BLUR_VARIANT
     int pp_waves = 512;    // TW_PP_WAVES: below this many waves of 96x8 tiles a level takes the plane-parallel kernel
+    int blur_nomask = 0;   // TW_BLUR_NOMASK
     int blur_small = -1;   // TW_BLUR_SMALL: force the small-grid tile choice of the 31-tap blur (-1: by grid size)
     int poly_variant = 1;  // 1: tw_polyexp_pk<N,8> (packed f32, default); 2: tw_polyexp_pk<N,16>; 0: tw_polyexp (scalar f32) — TW_POLY_VARIANT
     std::string err;
@@ -770,6 +771,7 @@ void launch_blur(tw_engine* e, hipStream_t st, int w, int h, int ld, long long p
     a.rot = 0;
     a.store_flow = level < 0 ? 1 : 0;  // level -1: the per-stage test entry point, which returns the flow as well
     a.m = e->win_m;
+    a.nomask = e->blur_nomask;
     a.c = e->wc;
     const int gy = (h + BS_TH - 1) / BS_TH;
     const bool wide = w > 480;  // 224-column tiles; narrow levels use 96-column tiles (less edge waste)
@@ -840,6 +842,15 @@ void launch_blur(tw_engine* e, hipStream_t st, int w, int h, int ld, long long p
             else if (small == 3) hipLaunchKernelGGL((tw_blur_solve4<15, 64, 16, 4, true>), grid, dim3(64), 0, st, a);
             else if (small == 4) hipLaunchKernelGGL((tw_blur_solve_pp<15, 64, 16, 8>), grid, dim3(320), 0, st, a);
             else hipLaunchKernelGGL((tw_blur_solve_pp<15, 128, 16, 8>), grid, dim3(640), 0, st, a);
+            return;
+        }
+        if (wide && e->blur_variant == 5 && w >= 960) {
+            // 480-column tiles (512 threads, 80 KB LDS, two workgroups per CU): 93.75 % of the columns of the vertical
+            // pass and of the lanes of the horizontal pass are useful (87.5 % with 224-column tiles), and 1920 / 960 /
+            // 3840-pixel rows are covered exactly (nine 224-column tiles cover 2016)
+            a.xsh = ((w + 16 + 479) / 480 == (w + 479) / 480) ? 16 : 0;
+            a.rot = a.xsh;
+            hipLaunchKernelGGL((tw_blur_solve4<15, 512, 16, 8, true>), dim3((w + a.xsh + 479) / 480, gy, npairs), dim3(512), 0, st, a);
             return;
         }
         // shift the tile grid 16 px left when that costs no extra tile column (see the kernel)
@@ -1287,6 +1298,7 @@ tw_status tw_engine_create(int device, const tw_params* params, int slots, tw_en
     if (const char* ev = getenv("TW_POLY_VARIANT")) e->poly_variant = atoi(ev);
     if (const char* ev = getenv("TW_BLUR_SMALL")) e->blur_small = atoi(ev);
     if (const char* ev = getenv("TW_PP_WAVES")) e->pp_waves = atoi(ev);
+    if (const char* ev = getenv("TW_BLUR_NOMASK")) e->blur_nomask = atoi(ev);
     if (const char* ev = getenv("TW_UPD_NY")) e->upd_ny = atoi(ev) == 1 ? 1 : 2;
     if (const char* ev = getenv("TW_LANES")) e->lanes = std::min(2, std::max(1, atoi(ev)));
     if (const char* ev = getenv("TW_LATENCY_STREAMS")) e->lat_streams = atoi(ev) ? 1 : 0;

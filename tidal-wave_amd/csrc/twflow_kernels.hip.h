@@ -1297,6 +1297,7 @@ struct BlurArgs {
     int store_flow;  // 1: store the flow of a refreshing launch too (nothing reads it: the refresh uses the value in
                      // registers and the next launch overwrites it; the engine stores only the last iteration's)
     int m;       // runtime m for the generic kernel
+    int nomask;  // A/B switch (TW_BLUR_NOMASK=1): compute the lanes that overhang the image as well
     WinCoef c;
 };
 
@@ -1328,7 +1329,10 @@ __global__ __launch_bounds__(COLS) __attribute__((amdgpu_waves_per_eu(4, 8))) vo
     float* __restrict__ flow = a.flow + (long long)z * 2 * a.fps;
 
     // ---- V ----
-    {
+    // Columns further than MH outside the image feed no valid output pixel (the tile grid overhangs the right edge, and
+    // the left one by xsh): their lanes are masked off — no loads, no arithmetic, no LDS stores.  The engine runs at
+    // the board's power limit, so an idle lane is a saving even where it does not shorten the instruction stream.
+    if (a.nomask || (x0 - HALO + tid >= -MH && x0 - HALO + tid <= a.w - 1 + MH)) {
         const unsigned xb = (unsigned)clampi(x0 - HALO + tid, 0, a.w - 1) * 4u;
         unsigned ro[NW];  // wave-uniform byte offsets of the clamped rows
 #pragma unroll
@@ -1372,7 +1376,8 @@ __global__ __launch_bounds__(COLS) __attribute__((amdgpu_waves_per_eu(4, 8))) vo
     constexpr int NITEM = TH * GROUPS;
     constexpr int ROUNDS = (NITEM + COLS - 1) / COLS;
     constexpr int WL = 4 + 2 * HALO;
-    constexpr int NPX = TH * TW / COLS;
+    constexpr int NPX = (TH * TW + COLS - 1) / COLS;  // the last round may be ragged (COLS = 512: 7.5 pixels per lane)
+    constexpr bool RAGGED = (TH * TW) % COLS != 0;
     // QPRE: the R0 coefficients of the lane's S-phase pixels do not depend on the flow — fetch them now, so that a
     // third of the refresh's loads move under the horizontal arithmetic (+1 % pairs/s; 110 VGPRs, still 4 waves/SIMD)
     float qpre[QPRE ? NPX : 1][5];
@@ -1381,7 +1386,7 @@ __global__ __launch_bounds__(COLS) __attribute__((amdgpu_waves_per_eu(4, 8))) vo
             const float* __restrict__ R0p = a.R + (long long)(2 * z) * 5 * a.ps;
 #pragma unroll
             for (int i = 0; i < NPX; i++) {
-                const int p = tid + i * COLS;
+                const int p = RAGGED ? min(tid + i * COLS, TH * TW - 1) : tid + i * COLS;
                 const int r = p / TW, c0 = p - r * TW + a.rot, cx = c0 >= TW ? c0 - TW : c0;
                 const int xc = clampi(x0 + cx, 0, a.w - 1), yc = min(y0 + r, a.h - 1);
                 const long long o = (long long)yc * a.ld + xc;
@@ -1394,7 +1399,8 @@ __global__ __launch_bounds__(COLS) __attribute__((amdgpu_waves_per_eu(4, 8))) vo
 #pragma unroll
     for (int rd = 0; rd < ROUNDS; rd++) {
         const int it = tid + rd * COLS;
-        if (it < NITEM) {
+        // (items wholly outside the image produce nothing that is stored: skipped, see V)
+        if (it < NITEM && (a.nomask || (x0 + 4 * (it % GROUPS) < a.w && x0 + 4 * (it % GROUPS) + 3 >= 0))) {
             const int r = it / GROUPS, q = it - r * GROUPS;
 #pragma unroll
             for (int ch = 0; ch < 5; ch++) {
@@ -1423,7 +1429,7 @@ __global__ __launch_bounds__(COLS) __attribute__((amdgpu_waves_per_eu(4, 8))) vo
 #pragma unroll
     for (int rd = 0; rd < ROUNDS; rd++) {
         const int it = tid + rd * COLS;
-        if (it < NITEM) {
+        if (it < NITEM && (a.nomask || (x0 + 4 * (it % GROUPS) < a.w && x0 + 4 * (it % GROUPS) + 3 >= 0))) {
             const int r = it / GROUPS, q = it - r * GROUPS;
 #pragma unroll
             for (int ch = 0; ch < 5; ch++) *(f32x4*)&sm[ch][r][HALO + 4 * q] = res[rd][ch];
@@ -1435,18 +1441,18 @@ __global__ __launch_bounds__(COLS) __attribute__((amdgpu_waves_per_eu(4, 8))) vo
     float* __restrict__ Mout = a.Mout + (long long)z * 5 * a.ps;
     const float* __restrict__ R0 = a.R + (long long)(2 * z) * 5 * a.ps;
     const float* __restrict__ R1 = R0 + 5 * a.ps;
-    static_assert((TH * TW) % COLS == 0, "pixels per lane must be whole");
     // Every lane always computes (on a clamped, valid pixel); only the stores are predicated, so the loop body
     // has no control flow and the gathers of SUNROLL pixels are in flight together.
 #pragma unroll
     for (int i = 0; i < NPX; i++) {
         if (i % SUNROLL == 0) __builtin_amdgcn_sched_barrier(0);  // SUNROLL pixels in flight
-        const int p = tid + i * COLS;
+        const bool mine = !RAGGED || tid + i * COLS < TH * TW;
+        const int p = mine ? tid + i * COLS : TH * TW - 1;
         // rotated by xsh within the row: the 64 consecutive pixels of a wave then start on a 128-byte boundary,
         // like the vertical phase's row segments (the tile itself starts xsh pixels left of one)
         const int r = p / TW, c0 = p - r * TW + a.rot, cx = c0 >= TW ? c0 - TW : c0;
         const int x = x0 + cx, y = y0 + r;
-        const bool valid = x >= 0 && x < a.w && y < a.h;
+        const bool valid = mine && x >= 0 && x < a.w && y < a.h;
         const int xc = clampi(x, 0, a.w - 1), yc = min(y, a.h - 1);
         const double g11 = sm[0][r][HALO + cx], g12 = sm[1][r][HALO + cx], g22 = sm[2][r][HALO + cx],
                      h1 = sm[3][r][HALO + cx], h2 = sm[4][r][HALO + cx];
