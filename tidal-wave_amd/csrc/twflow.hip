@@ -1167,10 +1167,17 @@ tw_status submit_common(tw_engine* e, const uint8_t* h_a, const uint8_t* h_b, co
         if (host_pinned(h_a) && host_pinned(h_b)) {
             // page-locked caller memory (tw_host_alloc or hipHostRegister): DMA straight from it.  The caller keeps
             // the buffers unchanged until tw_wait() of this ticket returns.
-            TW_HIP(e, hipMemcpy2DAsync(dst_a, (size_t)width, h_a, (size_t)stride, (size_t)width, (size_t)height,
-                                       hipMemcpyHostToDevice, e->copy_stream));
-            TW_HIP(e, hipMemcpy2DAsync(dst_b, (size_t)width, h_b, (size_t)stride, (size_t)width, (size_t)height,
-                                       hipMemcpyHostToDevice, e->copy_stream));
+            if (stride == width) {
+                // dense rows: plain 1-D transfers (the DMA engines; a pitched 2-D copy may run as a blit kernel on
+                // the CUs the flow kernels are using)
+                TW_HIP(e, hipMemcpyAsync(dst_a, h_a, (size_t)width * height, hipMemcpyHostToDevice, e->copy_stream));
+                TW_HIP(e, hipMemcpyAsync(dst_b, h_b, (size_t)width * height, hipMemcpyHostToDevice, e->copy_stream));
+            } else {
+                TW_HIP(e, hipMemcpy2DAsync(dst_a, (size_t)width, h_a, (size_t)stride, (size_t)width, (size_t)height,
+                                           hipMemcpyHostToDevice, e->copy_stream));
+                TW_HIP(e, hipMemcpy2DAsync(dst_b, (size_t)width, h_b, (size_t)stride, (size_t)width, (size_t)height,
+                                           hipMemcpyHostToDevice, e->copy_stream));
+            }
         } else {
             if (need > c->h_img_cap) {
                 if (c->h_img) (void)hipHostFree(c->h_img);

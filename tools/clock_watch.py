@@ -18,36 +18,36 @@ def read(path):
 
 
 def sources():
-    src = {}
+    """One dict of sysfs paths per AMD GPU of the host (a 1-GPU lease still sees every card in sysfs)."""
+    cards = []
     for dev in sorted(glob.glob("/sys/class/drm/card*/device")):
         if read(dev + "/vendor") != "0x1002":
             continue
-        src["sclk"] = dev + "/pp_dpm_sclk"
+        src = {"sclk": dev + "/pp_dpm_sclk"}
         for hw in glob.glob(dev + "/hwmon/hwmon*"):
-            for name in ("power1_average", "power1_input", "freq1_input", "temp1_input", "power1_cap"):
+            for name in ("power1_average", "power1_input", "freq1_input", "power1_cap"):
                 if read(hw + "/" + name) is not None:
                     src[name] = hw + "/" + name
-        break
-    return src
+        cards.append(src)
+    return cards
 
 
 def main():
     out = sys.argv[1]
     cmd = sys.argv[sys.argv.index("--") + 1:]
-    src = sources()
-    samples = []
+    cards = sources()
+    samples = [[] for _ in cards]
     stop = threading.Event()
 
     def loop():
         while not stop.is_set():
-            s = {"t": time.time()}
-            for k, p in src.items():
-                v = read(p)
-                if k == "sclk" and v:
-                    cur = [l for l in v.split("\n") if l.endswith("*")]
-                    v = cur[0] if cur else v
-                s[k] = v
-            samples.append(s)
+            now = time.time()
+            for i, src in enumerate(cards):
+                s = {"t": now}
+                for k in ("freq1_input", "power1_input", "power1_average"):
+                    if k in src:
+                        s[k] = read(src[k])
+                samples[i].append(s)
             time.sleep(0.05)
 
     th = threading.Thread(target=loop)
@@ -57,19 +57,35 @@ def main():
     t1 = time.time()
     stop.set()
     th.join()
-    json.dump({"sources": src, "t0": t0, "t1": t1, "rc": rc, "samples": samples}, open(out, "w"))
-    # short digest: the busiest second
+
     def num(x):
         try:
-            return float(str(x).split(":")[-1].replace("Mhz", "").replace("*", "").strip())
+            return float(x)
         except Exception:
             return None
-    for key in ("freq1_input", "sclk", "power1_average", "power1_input"):
-        vals = [num(s.get(key)) for s in samples if s.get(key) is not None]
-        vals = [v for v in vals if v is not None]
-        if vals:
-            print("%s: n=%d min=%.0f median=%.0f max=%.0f" % (key, len(vals), min(vals), sorted(vals)[len(vals) // 2], max(vals)))
-    print("power cap:", read(src.get("power1_cap", "")) if src.get("power1_cap") else None)
+
+    def series(i, key):
+        return [v for v in (num(s.get(key)) for s in samples[i]) if v is not None]
+
+    # the card the command ran on = the one that drew the most power
+    pkey = "power1_input" if any("power1_input" in c for c in cards) else "power1_average"
+    peak = [max(series(i, pkey) or [0]) for i in range(len(cards))]
+    busy = peak.index(max(peak)) if peak else 0
+    json.dump({"card_index": busy, "sources": cards[busy] if cards else {}, "t0": t0, "t1": t1, "rc": rc,
+               "power_cap_uW": read(cards[busy].get("power1_cap", "")) if cards else None,
+               "samples": samples[busy] if cards else []}, open(out, "w"))
+    if cards:
+        pw, fq = series(busy, pkey), series(busy, "freq1_input")
+        hot = [i for i, v in enumerate(pw) if v >= 0.9 * max(pw)]  # the loaded phase
+        print("card %d of %d; power cap %s uW" % (busy, len(cards), read(cards[busy].get("power1_cap", ""))))
+        if hot:
+            hp = sorted(pw[i] for i in hot)
+            print("loaded phase (power >= 90 %% of its maximum): %d samples, power median %.0f W (max %.0f W)" %
+                  (len(hot), hp[len(hp) // 2] / 1e6, hp[-1] / 1e6))
+            if len(fq) == len(pw):
+                hf = sorted(fq[i] for i in hot)
+                print("shader clock in the loaded phase: median %.0f MHz (min %.0f, max %.0f); idle / unloaded maximum %.0f MHz" %
+                      (hf[len(hf) // 2] / 1e6, hf[0] / 1e6, hf[-1] / 1e6, max(fq) / 1e6))
     sys.exit(rc)
 
 
