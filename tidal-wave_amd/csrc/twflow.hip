@@ -9,6 +9,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
 #include <float.h>
 #include <math.h>
 #include <stdio.h>
@@ -276,6 +277,45 @@ struct ProfPair {
     hipEvent_t a, b;
 };
 
+// Optional roctx ranges (TW_ROCTX=1): one range per batch and per pyramid level on the submitting thread, so that a
+// rocprofv3 --marker-trace timeline shows which launches belong to which batch / level (SURVEY §5 "tracing"; the
+// reference only times the call, which `seconds` preserves).  libroctx64 is loaded on demand: no link dependency.
+struct Roctx {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx()
+    {
+        const char* ev = getenv("TW_ROCTX");
+        if (!ev || !atoi(ev)) return;
+        void* h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("libroctx64.so.4", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) return;
+        push = (int (*)(const char*))dlsym(h, "roctxRangePushA");
+        pop = (int (*)())dlsym(h, "roctxRangePop");
+        if (!push || !pop) push = nullptr, pop = nullptr;
+    }
+};
+Roctx& roctx()
+{
+    static Roctx r;
+    return r;
+}
+struct RoctxRange {
+    bool on;
+    explicit RoctxRange(const char* fmt, int a = 0, int b = 0, int c = 0) : on(roctx().push != nullptr)
+    {
+        if (on) {
+            char buf[96];
+            snprintf(buf, sizeof(buf), fmt, a, b, c);
+            roctx().push(buf);
+        }
+    }
+    ~RoctxRange()
+    {
+        if (on) roctx().pop();
+    }
+};
+
 }  // namespace
 
 struct tw_engine {
@@ -304,6 +344,7 @@ struct tw_engine {
     int pyr_generic = 0;   // TW_PYR_GENERIC=1: always the generic pyramid kernel, 2: tw_pyr_level_lds for every level (A/B)
     int blur_variant = 4;  // 4: tw_blur_solve4 (default); 8: tw_blur_solve8 (packed f32) — TW_BLUR_VARIANT
     int pp_waves = 512;    // TW_PP_WAVES: below this many waves of 96x8 tiles a level takes the plane-parallel kernel
+    unsigned long long* dbg_stamps = nullptr;  // TW_DEBUG_STAMPS=1: phase stamps of tw_pyr_taps (diagnostic runs only)
     int blur_nomask = 0;   // TW_BLUR_NOMASK
     int blur_small = -1;   // TW_BLUR_SMALL: force the small-grid tile choice of the 31-tap blur (-1: by grid size)
     int poly_variant = 1;  // 1: tw_polyexp_pk<N,8> (packed f32, default); 2: tw_polyexp_pk<N,16>; 0: tw_polyexp (scalar f32) — TW_POLY_VARIANT
@@ -547,7 +588,8 @@ tw_status reserve_workspace(tw_engine* e, const Plan* pl, int span, bool need_im
         e->ws_elems = need;
     }
     if (e->lat_streams && need_lat > e->lat_cap) {
-        if (e->lat_I) (void)hipFree(e->lat_I);
+        if (e->dbg_stamps) (void)hipFree(e->dbg_stamps);
+    if (e->lat_I) (void)hipFree(e->lat_I);
         if (e->lat_R) (void)hipFree(e->lat_R);
         e->lat_I = e->lat_R = nullptr;
         e->lat_cap = 0;
@@ -692,10 +734,16 @@ void launch_pyr(tw_engine* e, hipStream_t st, const Plan* pl, int k, const uint8
         b.p = a;
         b.pd = (L.pitch_b / 4 + 1) | 1;
         b.aligned4 = (stride % 4 == 0) ? e->img_aligned4 : 0;
+        b.dbg = e->dbg_stamps;
         memset(b.kext, 0, sizeof(b.kext));
         memcpy(b.kext + 1, L.h_taps.data(), sizeof(float) * L.ksize);
         const size_t lds3 = ((size_t)L.nrows_max * (2 * PYR_TW) + (size_t)L.nrows_max * b.pd + 4) * 4;
-        hipLaunchKernelGGL(tw_pyr_taps, grid, dim3(256), lds3, st, b);
+        switch (L.ksize) {
+            case 9: hipLaunchKernelGGL(tw_pyr_taps<9>, grid, dim3(256), lds3, st, b); break;
+            case 19: hipLaunchKernelGGL(tw_pyr_taps<19>, grid, dim3(256), lds3, st, b); break;
+            case 39: hipLaunchKernelGGL(tw_pyr_taps<39>, grid, dim3(256), lds3, st, b); break;
+            default: hipLaunchKernelGGL(tw_pyr_taps<0>, grid, dim3(256), lds3, st, b); break;
+        }
         return;
     }
     if (L.pitch_b > 0 && e->pyr_generic != 1) {
@@ -932,6 +980,7 @@ tw_status flush_ctx(tw_engine* e, Ctx& c)
         }
     }
     const int n = (int)c.jobs.size();
+    RoctxRange batch_range("tw_batch %dx%d pairs=%d", c.w, c.h, n);
     const size_t npx = staged_image_bytes(c.w, c.h);  // staged images are 256-byte aligned
     long long stride = c.jobs[0].stride;
     if (c.any_host) {
@@ -996,6 +1045,7 @@ tw_status flush_ctx(tw_engine* e, Ctx& c)
         float* M1 = e->M[1] + ws_lane / 2 * 5 * lane;
         for (int k = pl->levels; k >= 0; k--) {
             const LevelPlan& L = pl->lv[k];
+            RoctxRange level_range("tw_level %d (%dx%d)", k, L.w, L.h);
             for (int j0 = lo; j0 < hi; j0 += L.chunk) {
                 const int nc = std::min(L.chunk, hi - j0);
                 // flow buffers: levels >= 1 keep every pair of the batch, level 0 only the lane's current chunk
@@ -1306,6 +1356,8 @@ tw_status tw_engine_create(int device, const tw_params* params, int slots, tw_en
     if (const char* ev = getenv("TW_BLUR_SMALL")) e->blur_small = atoi(ev);
     if (const char* ev = getenv("TW_PP_WAVES")) e->pp_waves = atoi(ev);
     if (const char* ev = getenv("TW_BLUR_NOMASK")) e->blur_nomask = atoi(ev);
+    if (const char* ev = getenv("TW_DEBUG_STAMPS"))
+        if (atoi(ev)) (void)hipMalloc((void**)&e->dbg_stamps, 64 * 4 * sizeof(unsigned long long));
     if (const char* ev = getenv("TW_UPD_NY")) e->upd_ny = atoi(ev) == 1 ? 1 : 2;
     if (const char* ev = getenv("TW_LANES")) e->lanes = std::min(2, std::max(1, atoi(ev)));
     if (const char* ev = getenv("TW_LATENCY_STREAMS")) e->lat_streams = atoi(ev) ? 1 : 0;
@@ -1353,6 +1405,7 @@ void tw_engine_destroy(tw_engine* e)
     if (e->d_count) (void)hipFree(e->d_count);
     if (e->d_grid) (void)hipFree(e->d_grid);
     if (e->Vd) (void)hipFree(e->Vd);
+    if (e->dbg_stamps) (void)hipFree(e->dbg_stamps);
     if (e->lat_I) (void)hipFree(e->lat_I);
     if (e->lat_R) (void)hipFree(e->lat_R);
     for (hipEvent_t ev : e->lat_ev) (void)hipEventDestroy(ev);
@@ -1692,6 +1745,14 @@ tw_status down_planes(tw_engine* e, float* h, const float* d, int ld, long long 
 }
 }  // namespace
 
+
+// diagnostic: the phase stamps of the last tw_pyr_taps launch (TW_DEBUG_STAMPS=1), 64 workgroups x 4 stamps
+extern "C" int tw_debug_stamps(tw_engine* e, unsigned long long* out)
+{
+    if (!e || !e->dbg_stamps || !out) return 0;
+    if (hipSetDevice(e->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return 0;
+    return hipMemcpy(out, e->dbg_stamps, 64 * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 256 : 0;
+}
 
 // occupancy report of the main kernels (workgroups per CU the runtime admits) — tools/kbench.py
 extern "C" int tw_debug_occupancy(char* buf, int cap)

@@ -381,9 +381,13 @@ struct PyrTapsArgs {
     PyrArgs p;
     int pd;  // dwords per staged row (odd: the two rows a wave filters start on different banks)
     int aligned4;
+    unsigned long long* dbg;  // diagnostic build only (TW_DEBUG_STAMPS): s_memtime at the phase boundaries of the first 64 workgroups
     float kext[PYR_KEXT];
 };
 
+// KS = the smoothing kernel size when it is one of the sizes a pyr_scale = 0.5 pyramid uses (9, 19, 39: the tap loops
+// unroll and their LDS reads are issued back to back instead of one round trip per group of taps), 0 = any size.
+template <int KS>
 __global__ __launch_bounds__(256) void tw_pyr_taps(PyrTapsArgs aa)
 {
     const PyrArgs& a = aa.p;
@@ -393,7 +397,9 @@ __global__ __launch_bounds__(256) void tw_pyr_taps(PyrTapsArgs aa)
     const int x0 = blockIdx.x * PYR_TW, y0 = blockIdx.y * PYR_TH;
     const uint8_t* __restrict__ src = a.srcs[blockIdx.z];
     float* __restrict__ dst = a.dst + blockIdx.z * a.dst_zs;
-    const int ksize = a.ksize, r = ksize >> 1;
+    if (aa.dbg && tid == 0 && blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z) < 64)
+        aa.dbg[(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 4] = __builtin_amdgcn_s_memtime();
+    const int ksize = KS ? KS : a.ksize, r = ksize >> 1;
     const int yA = y0, yB = min(y0 + PYR_TH - 1, a.h - 1);
     const int ylo = clampi(a.yofs[yA], 0, a.h0 - 1) - r;
     const int yhi = clampi(a.yofs[yB] + 1, 0, a.h0 - 1) + r;
@@ -459,6 +465,9 @@ __global__ __launch_bounds__(256) void tw_pyr_taps(PyrTapsArgs aa)
     }
     __syncthreads();
 
+    const unsigned blin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const bool stamp = aa.dbg && tid == 0 && blin < 64;
+    if (stamp) aa.dbg[blin * 4 + 1] = __builtin_amdgcn_s_memtime();
     // ---- row filter: columns X and X+1 of one output pixel per thread ----
     {
         const int q = tid & 31;
@@ -470,6 +479,7 @@ __global__ __launch_bounds__(256) void tw_pyr_taps(PyrTapsArgs aa)
             const unsigned* D = tile + rr * pd + (o >> 2);
             unsigned lo = D[0];
             float sA = 0.f, sB = 0.f;
+#pragma unroll
             for (int g = 0; g < ngroups; g++) {
                 const unsigned hi = D[g + 1];
                 const unsigned wd = __builtin_amdgcn_alignbyte(hi, lo, sh);
@@ -494,6 +504,7 @@ __global__ __launch_bounds__(256) void tw_pyr_taps(PyrTapsArgs aa)
     }
     __syncthreads();
 
+    if (stamp) aa.dbg[blin * 4 + 2] = __builtin_amdgcn_s_memtime();
     // ---- column filter at the sampled rows + resize combine (as tw_pyr_level) ----
     const int tx = tid & (PYR_TW - 1), ty = tid / PYR_TW;
     const int ox = x0 + tx, oy = y0 + ty;
@@ -506,6 +517,7 @@ __global__ __launch_bounds__(256) void tw_pyr_taps(PyrTapsArgs aa)
         const float* R = rowbuf + srow * P + 2 * tx;
         const f32x2 c = *(const f32x2*)R;
         float sa = kc[0] * c.x, sb = kc[0] * c.y;
+#pragma unroll
         for (int j = 1; j <= r; j++) {
             const f32x2 up = *(const f32x2*)(R + j * P), dn = *(const f32x2*)(R - j * P);
             sa += kc[j] * (up.x + dn.x);
@@ -535,6 +547,7 @@ __global__ __launch_bounds__(256) void tw_pyr_taps(PyrTapsArgs aa)
         out = t0 * a.beta[2 * oy] + t1 * a.beta[2 * oy + 1];
     }
     dst[(long long)oy * a.ld + ox] = out;
+    if (stamp) aa.dbg[blin * 4 + 3] = __builtin_amdgcn_s_memtime();
 }
 
 // -----------------------------------------------------------------------------------------------------
