@@ -535,3 +535,32 @@ def test_two_stream_lanes_gaussian_and_box(twflow, oracle, kw, monkeypatch):
     for (a, b), g in zip(imgs, got):
         wx, wy = oracle.farneback(a, b, oracle.default_params(**kw))
         assert g == oracle.span_scan(wx, wy, 5, 0.75)
+
+
+@pytest.mark.parametrize("env", [dict(TW_BLUR_SMALL="1"), dict(TW_BLUR_SMALL="2"), dict(TW_BLUR_SMALL="3"),
+                                 dict(TW_BLUR_SMALL="4"), dict(TW_BLUR_SMALL="5"), dict(TW_POLY_VARIANT="0"),
+                                 dict(TW_POLY_VARIANT="2"), dict(TW_LATENCY_STREAMS="0"),
+                                 dict(TW_LATENCY_MIN_PX="0", TW_ROCTX="1"), dict(TW_BLUR_NOMASK="1"),
+                                 dict(TW_BLUR_VARIANT="5"), dict(TW_PP_WAVES="100000")])
+def test_every_kernel_variant_behind_a_switch_is_bit_exact(twflow, oracle, env, monkeypatch):
+    """The A/B switches of DESIGN.md §7 select other kernels / schedules for the same arithmetic (small-grid blur
+    tiles, the plane-parallel blur, scalar / 240x16 polyexp, one- or two-stream single-pair schedule, 480-column
+    blur tiles, unmasked overhang lanes, roctx ranges): each of them must give the oracle's bits, on a single pair
+    (latency schedule) and in a batch, at a size with three pyramid levels and ragged tile edges."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    rng = np.random.default_rng(99)
+    shapes = [(301, 1003)] if "TW_BLUR_VARIANT" in env else [(301, 515), (140, 97)]
+    for h, w in shapes:
+        a = rand_img(rng, h, w)
+        b = np.roll(a, 2, axis=1)
+        b[h // 2: h // 2 + 20, w // 3: w // 3 + 40] = 30
+        wx, wy = oracle.farneback(a, b)
+        want = oracle.span_scan(wx, wy, 7, 1.0)
+        with twflow.Engine(0, twflow.default_params(), slots=3) as e:
+            gx, gy, _ = e.calculate_internal(a, b)           # one pair: latency schedule
+            tk = [e.submit(a, b, 7, 1.0) for _ in range(3)]  # a batch of three
+            got = [e.wait(t)["vector"] for t in tk]
+        assert_same(gx, wx, "flowx %r %dx%d" % (env, w, h))
+        assert_same(gy, wy, "flowy %r %dx%d" % (env, w, h))
+        assert got == [want, want, want]
