@@ -485,8 +485,11 @@ tw_status get_plan(tw_engine* e, int w0, int h0, Plan** out)
         // pairs per launch: enough 8-row x 240-column tiles of two images to cover the 256 CUs many times over
         const long long tiles = (long long)((L.w + PE_TW - 1) / PE_TW) * ((L.h + PE_TH - 1) / PE_TH) * 2;
         // measured at 1080p: 4096 -> 16384 tiles per launch is +11 % pairs/s (fewer tails and gaps), 16384 -> 34000
-        // (16 pairs per level-0 launch: 19440 blur workgroups = 18.98 rounds of the 1024 resident ones) another +2.5 %
-        long long target = 34000;
+        // (16 pairs per level-0 launch) another +2.5 %, 34000 -> a whole 64-pair batch per launch +1.5 %, a whole
+        // 128-pair batch +4 % (round 2): every kernel boundary costs a drain, a fill and an L2 write-back of the dirty
+        // M planes, and 288 GB of HBM make the workspace of a whole batch (23 GB at 128 x 1080p) a non-issue.  So a
+        // launch covers the whole batch unless that exceeds 300 000 tiles.
+        long long target = 300000;
         if (const char* ev = getenv("TW_CHUNK_TILES")) target = std::max(1, atoi(ev));
         long long c = (target + tiles - 1) / tiles;
         L.chunk = (int)std::min<long long>(std::max<long long>(c, 1), e->cap);
@@ -1046,8 +1049,11 @@ tw_status flush_ctx(tw_engine* e, Ctx& c)
         for (int k = pl->levels; k >= 0; k--) {
             const LevelPlan& L = pl->lv[k];
             RoctxRange level_range("tw_level %d (%dx%d)", k, L.w, L.h);
-            for (int j0 = lo; j0 < hi; j0 += L.chunk) {
-                const int nc = std::min(L.chunk, hi - j0);
+            // balanced launches: 64 pairs with a 63-pair chunk are 32 + 32, not 63 + 1
+            const int nlaunch = (hi - lo + L.chunk - 1) / L.chunk;
+            const int per = nlaunch > 0 ? (hi - lo + nlaunch - 1) / nlaunch : 1;
+            for (int j0 = lo; j0 < hi; j0 += per) {
+                const int nc = std::min(per, hi - j0);
                 // flow buffers: levels >= 1 keep every pair of the batch, level 0 only the lane's current chunk
                 float* flow_cur = e->flow[k] + (k == 0 ? (size_t)lane * L.chunk * 2 * L.ps : (size_t)j0 * 2 * L.ps);
                 const float* flow_prev =

@@ -8,7 +8,7 @@
 // queue, the per-GPU consumers, the uploads over PCIe and the engines.  Needs no edits for 8 GPUs: --devices 0
 // uses every device the box has.
 //
-//   bench_queue --pgm-dir DIR [--pairs 2048] [--devices 0] [--per-device 1] [--batch 64] [--warmup-batches 2]
+//   bench_queue --pgm-dir DIR [--pairs 2048] [--devices 0] [--per-device 1] [--batch 128] [--warmup-batches 2]
 //               [--pinned 1] [--files 0] [--span 10] [--threshold 5]
 // DIR holds pair_<i>_a.pgm / pair_<i>_b.pgm (i = 0..), written by bench.py / tests from tidal-wave_amd/synth.py.
 // Prints one JSON line.
@@ -30,7 +30,7 @@ using namespace twhost;
 namespace {
 struct Args {
     std::string dir;
-    int pairs = 2048, devices = 0, per_device = 1, batch = 64, warmup_batches = 2, pinned = 1, files = 0, span = 10;
+    int pairs = 2048, devices = 0, per_device = 1, batch = 128, warmup_batches = 2, pinned = 1, files = 0, span = 10;
     double threshold = 5.0;
 };
 

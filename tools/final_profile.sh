@@ -12,21 +12,21 @@ mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 timeout -k 10 600 python3 bench.py > "$out/bench.log" 2>&1; grep '^{' "$out/bench.log" | tail -1 > "$out/bench.json"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -o run -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > "$out/trace.log" 2>&1
-python3 tools/rocprof_summary.py "$out/trace" "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras (single stream, 256-pair steps = 4 engine batches of 64)" > "$out/kernel_trace_summary.md"
+python3 tools/rocprof_summary.py "$out/trace" "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras (single stream, 256-pair steps = 2 engine batches of 128, one launch per kernel and level for a whole batch)" > "$out/kernel_trace_summary.md"
 cp "$out"/trace/*kernel_stats.csv "$out/kernel_stats.csv" 2>/dev/null
 grep '^{' "$out/trace.log" | tail -1 > "$out/bench_under_rocprof.json"
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$out/pmc_$c" -o run -- python3 bench.py --steps 1 --warmup 1 --batch 64 --no-cpu-baseline --no-prof --no-extras > "$out/pmc_$c.log" 2>&1
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$out/pmc_$c" -o run -- python3 bench.py --steps 1 --warmup 1 --batch 128 --no-cpu-baseline --no-prof --no-extras > "$out/pmc_$c.log" 2>&1
 done
 python3 tools/pmc_traffic.py "$out/pmc_FETCH_SIZE" "$out/pmc_WRITE_SIZE" "$out/traffic.json" "$out/pmc_hbm_traffic.md"
 tools/sq_probe.sh "$out/sq_polyexp" 8 1 0 > "$out/sq_polyexp.txt" 2>&1
 TW_POLY_VARIANT=0 tools/sq_probe.sh "$out/sq_polyexp_scalar" 8 1 0 > "$out/sq_polyexp_scalar.txt" 2>&1
 tools/sq_probe.sh "$out/sq_blur_fused" 8 3 0 0 > "$out/sq_blur_fused.txt" 2>&1
 tools/sq_probe.sh "$out/sq_blur_last" 8 3 0 2 > "$out/sq_blur_last.txt" 2>&1
-python3 tools/sq_report.py "$out/sq_polyexp" tw_polyexp_pk 66355200 "tw_polyexp_pk<7,8> @ level 0, 16 pairs (32 images of 1920x1080) per launch" packed > "$out/polyexp_sq.md"
-python3 tools/sq_report.py "$out/sq_polyexp_scalar" "tw_polyexp<7>" 66355200 "tw_polyexp<7> (scalar f32, TW_POLY_VARIANT=0) @ level 0, 16 pairs per launch" > "$out/polyexp_scalar_sq.md"
-python3 tools/sq_report.py "$out/sq_blur_fused" tw_blur_solve4 33177600 "tw_blur_solve4<15,256,16,8> fused with the matrix refresh @ level 0, 16 pairs per launch" > "$out/blur_fused_sq.md"
-python3 tools/sq_report.py "$out/sq_blur_last" tw_blur_solve4 33177600 "tw_blur_solve4<15,256,16,8> last iteration (no refresh) @ level 0, 16 pairs per launch" > "$out/blur_last_sq.md"
+python3 tools/sq_report.py "$out/sq_polyexp" tw_polyexp_pk 265420800 "tw_polyexp_pk<7,8> @ level 0, 64 pairs (128 images of 1920x1080) per launch" packed > "$out/polyexp_sq.md"
+python3 tools/sq_report.py "$out/sq_polyexp_scalar" "tw_polyexp<7>" 265420800 "tw_polyexp<7> (scalar f32, TW_POLY_VARIANT=0) @ level 0, 64 pairs per launch" > "$out/polyexp_scalar_sq.md"
+python3 tools/sq_report.py "$out/sq_blur_fused" tw_blur_solve4 132710400 "tw_blur_solve4<15,256,16,8> fused with the matrix refresh @ level 0, 64 pairs per launch" > "$out/blur_fused_sq.md"
+python3 tools/sq_report.py "$out/sq_blur_last" tw_blur_solve4 132710400 "tw_blur_solve4<15,256,16,8> last iteration (no refresh) @ level 0, 64 pairs per launch" > "$out/blur_last_sq.md"
 python3 tools/clock_watch.py "$out/clock_power.json" -- python3 bench.py --steps 40 --warmup 4 --no-cpu-baseline --no-extras > "$out/clock_power.log" 2>&1
 python3 tools/latency.py 40 > "$out/latency.txt" 2>&1
 echo done; cut -c1-400 "$out/bench.json"
