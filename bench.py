@@ -422,12 +422,19 @@ def main():
             name = twflow.KERNEL_NAMES[kc]
             chunk = eng.level_chunk(W, H, 0)
             tr = traffic.get(name)
+            ppl = per_pair_launches * pairs_mine / n  # pairs per launch in this run
+            tr_bytes = tr_pairs = None
+            if isinstance(tr, dict) and tr.get("pairs_per_launch"):
+                # the PMC passes measured launches of tr_pairs pairs; traffic is linear in the pairs of a launch
+                tr_pairs = tr["pairs_per_launch"]
+                tr_bytes = round(tr["bytes_per_launch"] * ppl / tr_pairs)
             return {"kernel": name + " @level0 (1920x1080)", "bound": "hbm", "achieved": round(gbs, 1),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-                    "traffic": tr.get("bytes_per_launch") if isinstance(tr, dict) else tr,
-                    "traffic_pairs_per_launch": tr.get("pairs_per_launch") if isinstance(tr, dict) else None,
+                    "traffic": tr_bytes,
+                    "traffic_pairs_per_launch": tr_pairs,
                     "traffic_source": "profiles/traffic_latest.json (static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
-                                      "passes of an earlier run of this command, not a live counter)",
+                                      "passes of an earlier run of this command, not a live counter; measured on launches "
+                                      "of traffic_pairs_per_launch pairs and scaled to this run's pairs per launch)",
                     "bytes_model": "what the kernel as built must move per launch (blur+solve: 80 B/px for a launch "
                                    "fused with the matrix refresh, 28 B/px for the last one; polyexp 24 B/px)",
                     "algorithmic_bytes_per_launch": bytes_total / n,

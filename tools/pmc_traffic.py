@@ -41,7 +41,7 @@ def main():
     for prefix, name in NAMES.items():
         cand = [r for r in rows if r[0].startswith(prefix) and r[1] % per_pair[name] == 0]
         if cand:
-            big = max(cand, key=lambda r: r[2])  # the most frequent level-0 launch shape
+            big = max(cand, key=lambda r: (r[1], r[2]))  # the largest level-0 launch (a whole engine batch)
             out[name] = {"bytes_per_launch": round(big[3] + big[4]), "pairs_per_launch": big[1] // per_pair[name],
                          "read_bytes": round(big[3]), "write_bytes": round(big[4])}
     json.dump(out, open(sys.argv[3], "w"), indent=1)
