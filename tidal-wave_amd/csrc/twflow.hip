@@ -1591,7 +1591,7 @@ tw_status tw_host_alloc(tw_engine* e, size_t bytes, void** hptr)
 {
     if (!e || !hptr) return TW_E_BAD_PARAMETER;
     TW_HIP(e, hipSetDevice(e->device));
-    TW_HIP(e, hipHostMalloc(hptr, bytes, hipHostMallocDefault));
+    TW_HIP(e, hipHostMalloc(hptr, bytes, hipHostMallocPortable));  // usable by the engines of every device (one queue, N consumers)
     return TW_OK;
 }
 tw_status tw_host_free(tw_engine* e, void* hptr)
