@@ -564,3 +564,40 @@ def test_every_kernel_variant_behind_a_switch_is_bit_exact(twflow, oracle, env, 
         assert_same(gx, wx, "flowx %r %dx%d" % (env, w, h))
         assert_same(gy, wy, "flowy %r %dx%d" % (env, w, h))
         assert got == [want, want, want]
+
+
+def test_soak_many_sizes_plan_cache_eviction_and_mixed_batches(twflow, oracle):
+    """A service sees arbitrary sizes for hours: 90 distinct image sizes (the plan cache is emptied every 64), batches
+    that mix them, spans and thresholds that vary per batch, results collected out of order — every vector list must
+    equal the oracle's."""
+    rng = np.random.default_rng(424242)
+    sizes = []
+    while len(sizes) < 90:
+        hw = (int(rng.integers(20, 140)), int(rng.integers(20, 200)))
+        if hw not in sizes:
+            sizes.append(hw)
+    with twflow.Engine(0, twflow.default_params(), slots=4) as e:
+        for start in range(0, len(sizes), 6):
+            group = sizes[start:start + 6]
+            span, thr = int(rng.integers(3, 12)), float(rng.choice([0.25, 1.0, 2.5]))
+            jobs = []
+            for (h, w) in group:
+                a = rand_img(rng, h, w)
+                b = np.roll(a, int(rng.integers(1, 3)), axis=int(rng.integers(0, 2)))
+                jobs.append((a, b))
+            jobs = jobs + jobs[:2]  # two sizes come back later in the same group
+            tickets = []
+            for a, b in jobs:
+                try:
+                    tickets.append(e.submit(a, b, span, thr))
+                except twflow.TwError as ex:  # three batch contexts: collect the oldest, then go on
+                    assert ex.code == twflow.TW_E_BUSY
+                    for i, t in enumerate(tickets):
+                        if t is not None and not isinstance(t, dict):
+                            tickets[i] = e.wait(t)
+                    tickets.append(e.submit(a, b, span, thr))
+            for i in reversed(range(len(tickets))):
+                r = tickets[i] if isinstance(tickets[i], dict) else e.wait(tickets[i])
+                a, b = jobs[i]
+                wx, wy = oracle.farneback(a, b)
+                assert r["vector"] == oracle.span_scan(wx, wy, span, thr), "size %r" % (a.shape,)

@@ -466,6 +466,14 @@ tw_status get_plan(tw_engine* e, int w0, int h0, Plan** out)
         *out = it->second;
         return TW_OK;
     }
+    if (e->plans.size() >= 64) {
+        // a long-running service that sees arbitrary image sizes must not collect plans (and their device tables) for
+        // ever: every 64 new sizes the cache is emptied.  Queued launches still read the tables, so drain first.
+        TW_HIP(e, hipStreamSynchronize(e->stream));
+        TW_HIP(e, hipStreamSynchronize(e->stream2));
+        for (auto& kv : e->plans) free_plan(kv.second);
+        e->plans.clear();
+    }
     Plan* pl = new Plan();
     pl->w0 = w0;
     pl->h0 = h0;
