@@ -903,6 +903,15 @@ void launch_blur(tw_engine* e, hipStream_t st, int w, int h, int ld, long long p
             else hipLaunchKernelGGL((tw_blur_solve_pp<15, 128, 16, 8>), grid, dim3(640), 0, st, a);
             return;
         }
+        if (wide && (e->blur_variant == 60 || e->blur_variant == 61)) {
+            // plane pipeline through a two-plane LDS ring (tw_blur_solve6), A/B
+            a.xsh = ((w + 16 + 223) / 224 == (w + 223) / 224) ? 16 : 0;
+            a.rot = a.xsh;
+            const dim3 grid((w + a.xsh + 223) / 224, gy, npairs);
+            if (e->blur_variant == 60) hipLaunchKernelGGL((tw_blur_solve6<15, 256, 16, 8, 5>), grid, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((tw_blur_solve6<15, 256, 16, 8, 4>), grid, dim3(256), 0, st, a);
+            return;
+        }
         if (wide && e->blur_variant == 5 && w >= 960) {
             // 480-column tiles (512 threads, 80 KB LDS, two workgroups per CU): 93.75 % of the columns of the vertical
             // pass and of the lanes of the horizontal pass are useful (87.5 % with 224-column tiles), and 1920 / 960 /

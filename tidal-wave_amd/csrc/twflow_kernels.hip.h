@@ -1492,6 +1492,169 @@ __global__ __launch_bounds__(COLS) __attribute__((amdgpu_waves_per_eu(4, 8))) vo
 }
 
 // -----------------------------------------------------------------------------------------------------
+// tw_blur_solve6<MH,COLS,HALO,TH> : tw_blur_solve4's arithmetic as a PLANE PIPELINE (VERDICT r1 #5 / DESIGN §9 (a)):
+//   the five M planes go one after the other through a two-plane LDS ring (16 KB instead of 40 KB), the horizontal
+//   results of all planes stay in registers, the item owner solves its 2 x 4 pixels there, and only the two flow
+//   planes are staged in LDS (in the ring, free by then) for the lane-consecutive refresh.  One barrier per plane:
+//       V0 | H0 V1 | H1 V2 | H2 V3 | H3 V4 | H4 solve | refresh
+//   LDS no longer limits the residency; registers do (no next-plane window prefetch, R0 fetched after the last H).
+//   Same values, same order per value.
+// -----------------------------------------------------------------------------------------------------
+template <int MH, int COLS, int HALO, int TH, int WPE = 5>
+__global__ __launch_bounds__(COLS) __attribute__((amdgpu_waves_per_eu(WPE, 8))) void tw_blur_solve6(BlurArgs a)
+{
+    constexpr int TW = COLS - 2 * HALO;
+    constexpr int NW = TH + 2 * MH;
+    static_assert(2 * TH * COLS >= 2 * TH * TW, "the flow planes fit the ring");
+    __shared__ __attribute__((aligned(16))) float ring[2][TH][COLS];
+    const int tid = threadIdx.x;
+    int bx, by, z;
+    xcd_remap(bx, by, z);
+    const int x0 = bx * TW - a.xsh, y0 = by * TH;
+    const WinCoef& c = a.c;
+    const float* __restrict__ Min = a.Min + (long long)z * 5 * a.ps;
+    float* __restrict__ flow = a.flow + (long long)z * 2 * a.fps;
+
+    const bool vact = a.nomask || (x0 - HALO + tid >= -MH && x0 - HALO + tid <= a.w - 1 + MH);
+    const unsigned xb = (unsigned)clampi(x0 - HALO + tid, 0, a.w - 1) * 4u;
+    // vertical pass of one plane into one ring slot
+    auto vpass = [&](int ch) {
+        if (!vact) return;
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(Min + (long long)ch * a.ps);
+        float wa[NW];
+#pragma unroll
+        for (int i = 0; i < NW; i++)
+            wa[i] = bload(rs, xb, (unsigned)clampi(y0 - MH + i, 0, a.h - 1) * ((unsigned)a.ld * 4u));
+#pragma unroll
+        for (int r = 0; r < TH; r++) {
+            float s0 = wa[r + MH] * c.k[0];
+#pragma unroll
+            for (int i = 1; i <= MH; i++) s0 += (wa[r + MH + i] + wa[r + MH - i]) * c.k[i];
+            ring[ch & 1][r][tid] = s0;
+            if (r & 1) __builtin_amdgcn_sched_barrier(0);  // two rows in flight
+        }
+    };
+
+    constexpr int GROUPS = TW / 4;
+    constexpr int NITEM = TH * GROUPS;
+    constexpr int ROUNDS = (NITEM + COLS - 1) / COLS;
+    constexpr int WL = 4 + 2 * HALO;
+    f32x4 res[5][ROUNDS];
+    bool item_on[ROUNDS];
+    int item_r[ROUNDS], item_q[ROUNDS];
+#pragma unroll
+    for (int rd = 0; rd < ROUNDS; rd++) {
+        const int it = tid + rd * COLS;
+        item_r[rd] = it / GROUPS;
+        item_q[rd] = it - item_r[rd] * GROUPS;
+        item_on[rd] = it < NITEM && (a.nomask || (x0 + 4 * item_q[rd] < a.w && x0 + 4 * item_q[rd] + 3 >= 0));
+    }
+    auto hpass = [&](int ch) {
+#pragma unroll
+        for (int rd = 0; rd < ROUNDS; rd++) {
+            if (item_on[rd]) {
+                float v[WL];
+#pragma unroll
+                for (int u = 0; u < WL / 4; u++) {
+                    const f32x4 A = *(const f32x4*)&ring[ch & 1][item_r[rd]][4 * item_q[rd] + 4 * u];
+                    v[4 * u] = A[0];
+                    v[4 * u + 1] = A[1];
+                    v[4 * u + 2] = A[2];
+                    v[4 * u + 3] = A[3];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int li = HALO + j;
+                    float sum = v[li] * c.k[0];
+#pragma unroll
+                    for (int i = 1; i <= MH; i++) sum += c.k[i] * (v[li - i] + v[li + i]);
+                    res[ch][rd][j] = sum;
+                    if (j & 1) __builtin_amdgcn_sched_barrier(0);  // two pixels in flight
+                }
+                asm volatile("" : "+v"(res[ch][rd]));  // a finished round stays where it is (no sinking below the next one)
+            }
+        }
+    };
+
+    vpass(0);
+    __syncthreads();
+#pragma unroll
+    for (int ch = 0; ch < 5; ch++) {
+        hpass(ch);                    // reads slot ch & 1
+        __builtin_amdgcn_sched_barrier(0);
+        if (ch < 4) vpass(ch + 1);    // writes slot (ch + 1) & 1, which H(ch - 1) finished with before the last barrier
+        if (ch < 4) __syncthreads();
+    }
+
+    // ---- solve where the horizontal results are (item owner, 2 x 4 pixels), flows -> the ring slot H(3) used ----
+    // (slot 1 was last read by H(3), i.e. before the barrier that followed it; slot 0 is still being read by H(4))
+    float(*fl)[TH][COLS] = nullptr;
+    (void)fl;
+    constexpr int NPX = (TH * TW + COLS - 1) / COLS;
+    constexpr bool RAGGED = (TH * TW) % COLS != 0;
+    // R0 of the lane's refresh pixels: independent of the flow, fetched now (they fly under the solve)
+    float qpre[NPX][5];
+    if (a.update) {
+        const float* __restrict__ R0p = a.R + (long long)(2 * z) * 5 * a.ps;
+#pragma unroll
+        for (int i = 0; i < NPX; i++) {
+            const int p = RAGGED ? min(tid + i * COLS, TH * TW - 1) : tid + i * COLS;
+            const int r = p / TW, c0 = p - r * TW + a.rot, cx = c0 >= TW ? c0 - TW : c0;
+            const int xc = clampi(x0 + cx, 0, a.w - 1), yc = min(y0 + r, a.h - 1);
+            const long long o = (long long)yc * a.ld + xc;
+#pragma unroll
+            for (int cc = 0; cc < 5; cc++) qpre[i][cc] = R0p[o + cc * a.ps];
+        }
+    }
+    __syncthreads();  // H(4) is done everywhere: both slots are free
+#pragma unroll
+    for (int rd = 0; rd < ROUNDS; rd++) {
+        if (item_on[rd]) {
+            f32x4 fxv, fyv;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const double g11 = res[0][rd][j], g12 = res[1][rd][j], g22 = res[2][rd][j], h1 = res[3][rd][j],
+                             h2 = res[4][rd][j];
+                const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
+                fxv[j] = (float)((g11 * h2 - g12 * h1) * idet);
+                fyv[j] = (float)((g22 * h1 - g12 * h2) * idet);
+            }
+            *(f32x4*)&ring[0][item_r[rd]][HALO + 4 * item_q[rd]] = fxv;
+            *(f32x4*)&ring[1][item_r[rd]][HALO + 4 * item_q[rd]] = fyv;
+        }
+    }
+    __syncthreads();
+
+    // ---- store the flow / refresh M, lane-consecutive pixels ----
+    float* __restrict__ Mout = a.Mout + (long long)z * 5 * a.ps;
+    const float* __restrict__ R1 = a.R + (long long)(2 * z) * 5 * a.ps + 5 * a.ps;
+#pragma unroll
+    for (int i = 0; i < NPX; i++) {
+        if (i % 2 == 0) __builtin_amdgcn_sched_barrier(0);  // two pixels in flight
+        const bool mine = !RAGGED || tid + i * COLS < TH * TW;
+        const int p = mine ? tid + i * COLS : TH * TW - 1;
+        const int r = p / TW, c0 = p - r * TW + a.rot, cx = c0 >= TW ? c0 - TW : c0;
+        const int x = x0 + cx, y = y0 + r;
+        const bool valid = mine && x >= 0 && x < a.w && y < a.h;
+        const int xc = clampi(x, 0, a.w - 1), yc = min(y, a.h - 1);
+        const float fxv = ring[0][r][HALO + cx], fyv = ring[1][r][HALO + cx];
+        const long long o = (long long)yc * a.ld + xc;
+        if (valid && (!a.update || a.store_flow)) {
+            flow[o] = fxv;
+            flow[o + a.fps] = fyv;
+        }
+        if (a.update) {  // wave-uniform
+            float M[5];
+            update_matrices_core(qpre[i], R1, a.ps, a.ld, a.w, a.h, xc, yc, fxv, fyv, M);
+            if (valid) {
+#pragma unroll
+                for (int cc = 0; cc < 5; cc++) Mout[o + cc * a.ps] = M[cc];
+            }
+        }
+    }
+}
+
+// -----------------------------------------------------------------------------------------------------
 // tw_blur_solve_pp<MH,COLS,HALO,TH> : the same arithmetic for SMALL grids (one pair, coarse levels), where a launch
 //   is a single round of workgroups and its duration is one workgroup's serial V -> H -> S chain, not throughput.
 //   Plane-parallel: a workgroup has 5 x COLS threads, thread group g = tid / COLS owns plane g of M in the vertical
