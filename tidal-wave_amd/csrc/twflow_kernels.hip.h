@@ -1505,7 +1505,6 @@ __global__ __launch_bounds__(COLS) __attribute__((amdgpu_waves_per_eu(WPE, 8))) 
 {
     constexpr int TW = COLS - 2 * HALO;
     constexpr int NW = TH + 2 * MH;
-    static_assert(2 * TH * COLS >= 2 * TH * TW, "the flow planes fit the ring");
     __shared__ __attribute__((aligned(16))) float ring[2][TH][COLS];
     const int tid = threadIdx.x;
     int bx, by, z;
@@ -1586,10 +1585,8 @@ __global__ __launch_bounds__(COLS) __attribute__((amdgpu_waves_per_eu(WPE, 8))) 
         if (ch < 4) __syncthreads();
     }
 
-    // ---- solve where the horizontal results are (item owner, 2 x 4 pixels), flows -> the ring slot H(3) used ----
-    // (slot 1 was last read by H(3), i.e. before the barrier that followed it; slot 0 is still being read by H(4))
-    float(*fl)[TH][COLS] = nullptr;
-    (void)fl;
+    // ---- solve where the horizontal results are (item owner, 2 x 4 pixels); the flows go to the ring, which is free
+    // once every wave has finished H(4) ----
     constexpr int NPX = (TH * TW + COLS - 1) / COLS;
     constexpr bool RAGGED = (TH * TW) % COLS != 0;
     // R0 of the lane's refresh pixels: independent of the flow, fetched now (they fly under the solve)
