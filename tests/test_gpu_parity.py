@@ -602,3 +602,32 @@ def test_soak_many_sizes_plan_cache_eviction_and_mixed_batches(twflow, oracle):
                 a, b = jobs[i]
                 wx, wy = oracle.farneback(a, b)
                 assert r["vector"] == oracle.span_scan(wx, wy, span, thr), "size %r" % (a.shape,)
+
+
+def test_8k_pair_properties_and_size_limit(twflow):
+    """Maximum sizes: a 7680x4320 pair (33 Mpixel, five pyramid levels with pyrLevels 4) — too large for the CPU
+    oracle in a test, so size-independent properties: identical images report nothing, a painted rectangle is
+    SUSPICIOUS with every hit inside the rectangle's neighbourhood, the dense flow far from it stays ~0 and the
+    result is reproducible; beyond 2^28 pixels the engine refuses (32-bit plane offsets)."""
+    h, w = 4320, 7680
+    yy, xx = np.mgrid[0:h, 0:w]
+    a = ((np.sin(xx / 37.0) + np.cos(yy / 23.0)) * 50 + 128 + ((xx // 64 + yy // 64) % 2) * 20).astype(np.uint8)
+    b = a.copy()
+    b[2000:2300, 3000:3600] = 0
+    with twflow.Engine(0, twflow.default_params(pyrLevels=4), slots=2) as e:
+        assert e.num_levels(w, h) == 4
+        t1, t2 = e.submit(a, a), e.submit(a, b)
+        r1, r2 = e.wait(t1), e.wait(t2)
+        assert r1["status"] == "OK" and r1["vector"] == []
+        assert r2["status"] == "SUSPICIOUS" and len(r2["vector"]) > 20
+        for x, y, dx, dy in r2["vector"]:
+            assert 2600 <= x <= 4000 and 1600 <= y <= 2700, (x, y)
+        gx, gy, _ = e.calculate_internal(a, b)
+        assert np.isfinite(gx).all() and np.isfinite(gy).all()
+        assert float(np.abs(gx[:1000, :2000]).max()) < 0.5 and float(np.abs(gy[3200:, 5000:]).max()) < 0.5
+        r3 = e.diff(a, b)
+        assert r3["vector"] == r2["vector"]
+        big = np.zeros((16385, 16384), np.uint8)
+        with pytest.raises(twflow.TwError) as ei:
+            e.submit(big, big)
+        assert ei.value.code == twflow.TW_E_UNSUPPORTED

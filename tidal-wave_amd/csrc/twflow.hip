@@ -1163,6 +1163,12 @@ tw_status check_dims(tw_engine* e, int width, int height)
         e->err = "bad image size";
         return TW_E_BAD_PARAMETER;
     }
+    if ((long long)width * height > (1ll << 28)) {
+        // the stencil kernels address a plane with 32-bit byte offsets (raw buffer loads): planes stay below 4 GiB
+        // with room for the row pitch; 268 Mpixel (16384 x 16384) is far beyond any screenshot
+        e->err = "image larger than 2^28 pixels";
+        return TW_E_UNSUPPORTED;
+    }
     return TW_OK;
 }
 
