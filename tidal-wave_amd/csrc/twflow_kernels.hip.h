@@ -1340,6 +1340,14 @@ __global__ __launch_bounds__(COLS) __attribute__((amdgpu_waves_per_eu(4, 8))) vo
     const WinCoef& c = a.c;
     const float* __restrict__ Min = a.Min + (long long)z * 5 * a.ps;
     float* __restrict__ flow = a.flow + (long long)z * 2 * a.fps;
+    // A tile that overhangs the image by 32 columns or more (the last tile column: 144 of 224 columns at 1920, 64 of
+    // 224 at 960) is PARTIAL: its horizontal items and its solve / refresh pixels are re-indexed over the valid
+    // columns [cx0, cx0 + vw) only, so that whole waves drop out instead of lanes (wave-uniform switch; the index
+    // arithmetic of a full tile keeps its compile-time divisors).
+    const int cx0 = max(0, -x0), vw = min(TW, a.w - x0) - cx0;
+    const bool partial = !a.nomask && vw <= TW - 32;
+    const int gq0 = cx0 >> 2, gv = ((cx0 + vw + 3) >> 2) - gq0;  // 4-pixel groups with a valid pixel
+    const float inv_gv = 1.f / (float)gv, inv_vw = 1.f / (float)vw;
 
     // ---- V ----
     // Columns further than MH outside the image feed no valid output pixel (the tile grid overhangs the right edge, and
@@ -1399,8 +1407,17 @@ __global__ __launch_bounds__(COLS) __attribute__((amdgpu_waves_per_eu(4, 8))) vo
             const float* __restrict__ R0p = a.R + (long long)(2 * z) * 5 * a.ps;
 #pragma unroll
             for (int i = 0; i < NPX; i++) {
-                const int p = RAGGED ? min(tid + i * COLS, TH * TW - 1) : tid + i * COLS;
-                const int r = p / TW, c0 = p - r * TW + a.rot, cx = c0 >= TW ? c0 - TW : c0;
+                int r, cx;
+                if (partial) {
+                    const int p = min(tid + i * COLS, TH * vw - 1);
+                    r = (int)(((float)p + 0.5f) * inv_vw);
+                    cx = cx0 + p - r * vw;
+                } else {
+                    const int p = RAGGED ? min(tid + i * COLS, TH * TW - 1) : tid + i * COLS;
+                    r = p / TW;
+                    const int c0 = p - r * TW + a.rot;
+                    cx = c0 >= TW ? c0 - TW : c0;
+                }
                 const int xc = clampi(x0 + cx, 0, a.w - 1), yc = min(y0 + r, a.h - 1);
                 const long long o = (long long)yc * a.ld + xc;
 #pragma unroll
@@ -1413,8 +1430,18 @@ __global__ __launch_bounds__(COLS) __attribute__((amdgpu_waves_per_eu(4, 8))) vo
     for (int rd = 0; rd < ROUNDS; rd++) {
         const int it = tid + rd * COLS;
         // (items wholly outside the image produce nothing that is stored: skipped, see V)
-        if (it < NITEM && (a.nomask || (x0 + 4 * (it % GROUPS) < a.w && x0 + 4 * (it % GROUPS) + 3 >= 0))) {
-            const int r = it / GROUPS, q = it - r * GROUPS;
+        int r, q;
+        bool on;
+        if (partial) {
+            on = it < TH * gv;
+            r = (int)(((float)it + 0.5f) * inv_gv);
+            q = gq0 + it - r * gv;
+        } else {
+            r = it / GROUPS;
+            q = it - r * GROUPS;
+            on = it < NITEM && (a.nomask || (x0 + 4 * q < a.w && x0 + 4 * q + 3 >= 0));
+        }
+        if (on) {
 #pragma unroll
             for (int ch = 0; ch < 5; ch++) {
                 float v[WL];
@@ -1442,8 +1469,18 @@ __global__ __launch_bounds__(COLS) __attribute__((amdgpu_waves_per_eu(4, 8))) vo
 #pragma unroll
     for (int rd = 0; rd < ROUNDS; rd++) {
         const int it = tid + rd * COLS;
-        if (it < NITEM && (a.nomask || (x0 + 4 * (it % GROUPS) < a.w && x0 + 4 * (it % GROUPS) + 3 >= 0))) {
-            const int r = it / GROUPS, q = it - r * GROUPS;
+        int r, q;
+        bool on;
+        if (partial) {
+            on = it < TH * gv;
+            r = (int)(((float)it + 0.5f) * inv_gv);
+            q = gq0 + it - r * gv;
+        } else {
+            r = it / GROUPS;
+            q = it - r * GROUPS;
+            on = it < NITEM && (a.nomask || (x0 + 4 * q < a.w && x0 + 4 * q + 3 >= 0));
+        }
+        if (on) {
 #pragma unroll
             for (int ch = 0; ch < 5; ch++) *(f32x4*)&sm[ch][r][HALO + 4 * q] = res[rd][ch];
         }
@@ -1459,11 +1496,23 @@ __global__ __launch_bounds__(COLS) __attribute__((amdgpu_waves_per_eu(4, 8))) vo
 #pragma unroll
     for (int i = 0; i < NPX; i++) {
         if (i % SUNROLL == 0) __builtin_amdgcn_sched_barrier(0);  // SUNROLL pixels in flight
-        const bool mine = !RAGGED || tid + i * COLS < TH * TW;
-        const int p = mine ? tid + i * COLS : TH * TW - 1;
-        // rotated by xsh within the row: the 64 consecutive pixels of a wave then start on a 128-byte boundary,
-        // like the vertical phase's row segments (the tile itself starts xsh pixels left of one)
-        const int r = p / TW, c0 = p - r * TW + a.rot, cx = c0 >= TW ? c0 - TW : c0;
+        bool mine;
+        int r, cx;
+        if (partial) {
+            if (i * COLS >= TH * vw) break;  // wave-uniform: the valid pixels of a partial tile take fewer rounds
+            mine = tid + i * COLS < TH * vw;
+            const int p = mine ? tid + i * COLS : TH * vw - 1;
+            r = (int)(((float)p + 0.5f) * inv_vw);
+            cx = cx0 + p - r * vw;
+        } else {
+            mine = !RAGGED || tid + i * COLS < TH * TW;
+            const int p = mine ? tid + i * COLS : TH * TW - 1;
+            // rotated by xsh within the row: the 64 consecutive pixels of a wave then start on a 128-byte boundary,
+            // like the vertical phase's row segments (the tile itself starts xsh pixels left of one)
+            r = p / TW;
+            const int c0 = p - r * TW + a.rot;
+            cx = c0 >= TW ? c0 - TW : c0;
+        }
         const int x = x0 + cx, y = y0 + r;
         const bool valid = mine && x >= 0 && x < a.w && y < a.h;
         const int xc = clampi(x, 0, a.w - 1), yc = min(y, a.h - 1);
