@@ -542,7 +542,7 @@ def test_two_stream_lanes_gaussian_and_box(twflow, oracle, kw, monkeypatch):
                                  dict(TW_POLY_VARIANT="2"), dict(TW_LATENCY_STREAMS="0"),
                                  dict(TW_LATENCY_MIN_PX="0", TW_ROCTX="1"), dict(TW_BLUR_NOMASK="1"),
                                  dict(TW_BLUR_VARIANT="5"), dict(TW_BLUR_VARIANT="60"), dict(TW_BLUR_VARIANT="61"),
-                                 dict(TW_PP_WAVES="100000")])
+                                 dict(TW_PP_WAVES="100000"), dict(TW_CHUNK_TILES="100"), dict(TW_LANES="2", TW_CHUNK_TILES="100")])
 def test_every_kernel_variant_behind_a_switch_is_bit_exact(twflow, oracle, env, monkeypatch):
     """The A/B switches of DESIGN.md §7 select other kernels / schedules for the same arithmetic (small-grid blur
     tiles, the plane-parallel blur, scalar / 240x16 polyexp, one- or two-stream single-pair schedule, 480-column
