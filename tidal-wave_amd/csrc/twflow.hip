@@ -1593,12 +1593,15 @@ tw_status tw_flow_u8(tw_engine* e, const uint8_t* expect, const uint8_t* target,
     if ((r = get_plan(e, width, height, &pl))) return r;
     const LevelPlan& L0 = pl->lv[0];
     const float* f = e->flow[0];
+    // on the engine's own stream, then one host-side synchronise of it (copies on the null stream are never
+    // followed by one, and this runtime keeps a little bookkeeping per command until a stream is synchronised)
     if (flowx)
-        TW_HIP(e, hipMemcpy2D(flowx, (size_t)width * 4, f, (size_t)L0.ld * 4, (size_t)width * 4, height,
-                              hipMemcpyDeviceToHost));
+        TW_HIP(e, hipMemcpy2DAsync(flowx, (size_t)width * 4, f, (size_t)L0.ld * 4, (size_t)width * 4, height,
+                                   hipMemcpyDeviceToHost, e->stream));
     if (flowy)
-        TW_HIP(e, hipMemcpy2D(flowy, (size_t)width * 4, f + L0.ps, (size_t)L0.ld * 4, (size_t)width * 4, height,
-                              hipMemcpyDeviceToHost));
+        TW_HIP(e, hipMemcpy2DAsync(flowy, (size_t)width * 4, f + L0.ps, (size_t)L0.ld * 4, (size_t)width * 4, height,
+                                   hipMemcpyDeviceToHost, e->stream));
+    TW_HIP(e, hipStreamSynchronize(e->stream));
     return TW_OK;
 }
 
