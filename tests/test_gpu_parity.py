@@ -659,3 +659,22 @@ def test_host_uploads_do_not_grow_the_process(twflow):
                 if it == 40:
                     base = rss_mb()
             assert rss_mb() - base < 8.0, "resident set grew by %.1f MB over 10 240 pairs" % (rss_mb() - base)
+
+
+def test_out_of_memory_is_reported_and_the_engine_recovers(twflow, oracle, monkeypatch):
+    """A workspace that cannot be allocated (here: a whole 256-pair batch of 8K images in one launch, ~900 GB) is
+    TW_E_NOMEM for that batch — and nothing more: the HIP error is consumed where it is reported (it used to
+    resurface at the next launch check) and smaller work runs afterwards."""
+    monkeypatch.setenv("TW_CHUNK_TILES", "100000000")
+    rng = np.random.default_rng(8)
+    big = rng.integers(0, 256, (4320, 7680), dtype=np.uint8)
+    a = rand_img(rng, 90, 120)
+    b = np.roll(a, 1, axis=0)
+    want = oracle.span_scan(*oracle.farneback(a, b), 5, 0.5)
+    with twflow.Engine(0, twflow.default_params(), slots=256) as e:
+        assert e.diff(a, b, 5, 0.5)["vector"] == want
+        with pytest.raises(twflow.TwError) as ei:
+            e.wait(e.submit(big, big))
+        assert ei.value.code == twflow.TW_E_NOMEM
+        for _ in range(3):
+            assert e.diff(a, b, 5, 0.5)["vector"] == want

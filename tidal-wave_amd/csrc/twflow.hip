@@ -383,6 +383,7 @@ namespace {
     do {                                                                                  \
         hipError_t _err = (call);                                                         \
         if (_err != hipSuccess) {                                                         \
+            (void)hipGetLastError(); /* the failure is reported here: do not leave it for a later launch check */ \
             (e)->err = std::string(#call) + ": " + hipGetErrorString(_err);               \
             return _err == hipErrorOutOfMemory ? TW_E_NOMEM : TW_E_DEVICE;                \
         }                                                                                 \
