@@ -222,3 +222,23 @@ def test_queue_sharded_driver_in_memory_and_from_files(tmp_path):
         assert out["errors"] == 0 and out["report"] == {"request": n, "data": n, "error": 0}, out
         assert out["flagged_vectors"] == want, (extra, out["flagged_vectors"], want)
         assert out["pairs_per_s"] > 0 and out["width"] == 1920
+
+
+def test_image_decoders_survive_mutated_files_under_asan(tmp_path):
+    """cv::imread never crashes the service on a damaged file (it returns an empty Mat -> "Can't open <path>",
+    src/opticalflow.cpp:37-48).  The host decoders get the same treatment: 1 500 random mutations / truncations of
+    each fixture (PNG, JPEG, PGM) through load_gray under AddressSanitizer + UBSan — every one is either decoded to
+    w*h bytes or rejected, with no sanitizer report."""
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    r = subprocess.run(["make", "-s", "-C", HOST, "asan_fuzz"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    g = os.path.join(ROOT, "tests", "golden")
+    seeds = [os.path.join(g, "tree", "expected", "scenario2", "capture2.png"),
+             os.path.join(g, "tree", "expected", "scenario1", "capture1.jpg"),
+             os.path.join(g, "expected_scenario2_capture2.pgm")]
+    r = subprocess.run([os.path.join(HOST, "build", "fuzz_decode"), "1500", str(tmp_path / "scratch.bin")] + seeds,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]
+    assert "asan fuzz: decoded" in r.stdout
