@@ -277,8 +277,21 @@ struct Staged {
     bool done = false;  // response pushed
 };
 
+// the two imreads of a pair are independent: the decode pool runs them as separate tasks (task = 2 * job + image)
+void decode_one(Staged& s, int which, int* tw, int* th, std::string* err)
+{
+    if (s.req.raw.expect) return;
+    if (which == 0) {
+        if (s.req.expect_image.empty()) { *err = "ExpectImagePath is empty."; return; }
+        if (!load_gray(s.req.expect_image, s.a, s.w, s.h)) *err = "Can't open " + s.req.expect_image;
+    } else {
+        if (s.req.target_image.empty()) { *err = "TargetImagePath is empty."; return; }
+        if (!load_gray(s.req.target_image, s.b, *tw, *th)) *err = "Can't open " + s.req.target_image;
+    }
+}
+
 // OpticalFlow::calculate up to (not including) calculateInternal: src/opticalflow.cpp:20-68
-void prepare(Staged& s)
+void prepare(Staged& s, int tw, int th, const std::string& err_a, const std::string& err_b)
 {
     if (s.req.raw.expect) {  // in-memory pair: nothing to decode
         const RawPair& r = s.req.raw;
@@ -290,11 +303,11 @@ void prepare(Staged& s)
         s.stride = r.stride;
         return;
     }
+    // the reference checks and opens the expected image first (src/opticalflow.cpp:26-48): its error wins
     if (s.req.expect_image.empty()) { s.err = "ExpectImagePath is empty."; return; }
     if (s.req.target_image.empty()) { s.err = "TargetImagePath is empty."; return; }
-    int tw = 0, th = 0;
-    if (!load_gray(s.req.expect_image, s.a, s.w, s.h)) { s.err = "Can't open " + s.req.expect_image; return; }
-    if (!load_gray(s.req.target_image, s.b, tw, th)) { s.err = "Can't open " + s.req.target_image; return; }
+    if (!err_a.empty()) { s.err = err_a; return; }
+    if (!err_b.empty()) { s.err = err_b; return; }
     if (abs(s.h - th) > 5 || abs(s.w - tw) > 5) { s.err = "Don't match image size"; return; }
     if (s.h != th || s.w != tw) {
         std::vector<uint8_t> r;
@@ -381,15 +394,22 @@ void Consumer::run()
         // decode pool: once the flow runs on the GPU the two imreads of a pair are > 99 % of the wall time
         // (SURVEY §8 f1), so the pairs of a batch are decoded side by side
         {
-            const size_t nt = std::min(jobs.size(), (size_t)decode_threads_);
+            const size_t ntask = 2 * jobs.size();
+            const size_t nt = std::min(ntask, (size_t)decode_threads_);
+            std::vector<int> tw(jobs.size(), 0), th(jobs.size(), 0);
+            std::vector<std::string> ea(jobs.size()), eb(jobs.size());
             std::atomic<size_t> next{0};
             auto worker = [&] {
-                for (size_t i = next++; i < jobs.size(); i = next++) prepare(jobs[i]);
+                for (size_t i = next++; i < ntask; i = next++) {
+                    const size_t j = i >> 1;
+                    decode_one(jobs[j], (int)(i & 1), &tw[j], &th[j], (i & 1) ? &eb[j] : &ea[j]);
+                }
             };
             std::vector<std::thread> pool;
             for (size_t t = 1; t < nt; t++) pool.emplace_back(worker);
             worker();
             for (std::thread& t : pool) t.join();
+            for (size_t j = 0; j < jobs.size(); j++) prepare(jobs[j], tw[j], th[j], ea[j], eb[j]);
         }
         // one engine batch is homogeneous in size: group equal sizes so that a mixed queue makes few batches
         // (responses are delivered in completion order anyway, like the reference's)
@@ -444,7 +464,8 @@ void Manager::start(const Parameter& p)
         if (const char* ev = getenv("TW_CONSUMERS_PER_DEVICE")) per_dev = atoi(ev);
     if (per_dev <= 0) per_dev = 1;
     const int n = std::max(1, ndev > 0 ? std::min(p.numThreads, ndev * per_dev) : 1);
-    const int batch = p.batch > 0 ? std::min(256, p.batch) : std::max(1, std::min(32, p.numThreads * 2));
+    // (a batch also bounds how many images decode side by side: 32 pairs = 64 decode tasks for the pool)
+    const int batch = p.batch > 0 ? std::min(256, p.batch) : 32;
     // decode threads per consumer: TW_DECODE_THREADS, else the host cores shared between the consumers
     int dec = 0;
     if (const char* ev = getenv("TW_DECODE_THREADS")) dec = atoi(ev);

@@ -57,7 +57,7 @@ struct Parameter {
     int numThreads = 4;
     tw_params optParam;
     // not in the reference: consumers that share one GPU (0: TW_CONSUMERS_PER_DEVICE, default 1) and the engine
-    // batch of a consumer (0: min(32, 2*numThreads)).  The consumer count is min(numThreads, devices * perDevice).
+    // batch of a consumer (0: 32).  The consumer count is min(numThreads, devices * perDevice).
     int consumersPerDevice = 0;
     int batch = 0;
 };

@@ -21,9 +21,14 @@ def main():
     os.makedirs(os.path.join(d, "expected", "s"))
     os.makedirs(os.path.join(d, "target", "s"))
     for i in range(n):
-        a, b = synth.make_pair(i % 4, 1080, 1920)
-        Image.fromarray(a).save(os.path.join(d, "expected", "s", "p%03d.png" % i), compress_level=3)
-        Image.fromarray(b).save(os.path.join(d, "target", "s", "p%03d.png" % i), compress_level=3)
+        pe, pt = os.path.join(d, "expected", "s", "p%04d.png" % i), os.path.join(d, "target", "s", "p%04d.png" % i)
+        if i < 4:
+            a, b = synth.make_pair(i, 1080, 1920)
+            Image.fromarray(a).save(pe, compress_level=3)
+            Image.fromarray(b).save(pt, compress_level=3)
+        else:  # the four distinct pairs again (hard links: the decoder reads and inflates every file all the same)
+            os.link(os.path.join(d, "expected", "s", "p%04d.png" % (i % 4)), pe)
+            os.link(os.path.join(d, "target", "s", "p%04d.png" % (i % 4)), pt)
     js = ("var T=require('./index'); var t0=Date.now(); var n=0;"
           "var t=T.create(process.argv[1],{expectDir:process.argv[2], numThreads:8});"
           "t.on('data',function(){n++}); t.on('error',function(e){console.error(JSON.stringify(e))});"
