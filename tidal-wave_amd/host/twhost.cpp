@@ -144,21 +144,31 @@ static bool decode_png(const std::vector<uint8_t>& d, std::vector<uint8_t>& img,
         uint8_t* row = &raw[pass_off + (rowbytes + 1) * (size_t)y];
         const int ft = row[0];
         uint8_t* cur = row + 1;
-        for (size_t i = 0; i < rowbytes; i++) {
-            const int a = i >= fbpp ? cur[i - fbpp] : 0, b = prev[i], c = i >= fbpp ? prev[i - fbpp] : 0;
-            int v = cur[i];
-            switch (ft) {
-                case 0: break;
-                case 1: v += a; break;
-                case 2: v += b; break;
-                case 3: v += (a + b) >> 1; break;
-                case 4: {
+        const uint8_t* pv = prev.data();
+        // one loop per filter type (the type is per row; a switch per byte made the unfilter, not the inflate, the
+        // cost of a decode); the first fbpp bytes have no left neighbour
+        const size_t head = std::min(fbpp, rowbytes);
+        switch (ft) {
+            case 0: break;
+            case 1:
+                for (size_t i = head; i < rowbytes; i++) cur[i] = (uint8_t)(cur[i] + cur[i - fbpp]);
+                break;
+            case 2:
+                for (size_t i = 0; i < rowbytes; i++) cur[i] = (uint8_t)(cur[i] + pv[i]);
+                break;
+            case 3:
+                for (size_t i = 0; i < head; i++) cur[i] = (uint8_t)(cur[i] + (pv[i] >> 1));
+                for (size_t i = head; i < rowbytes; i++) cur[i] = (uint8_t)(cur[i] + ((cur[i - fbpp] + pv[i]) >> 1));
+                break;
+            case 4:
+                for (size_t i = 0; i < head; i++) cur[i] = (uint8_t)(cur[i] + pv[i]);  // a = c = 0: the predictor is b
+                for (size_t i = head; i < rowbytes; i++) {
+                    const int a = cur[i - fbpp], b = pv[i], c = pv[i - fbpp];
                     const int pa = abs(b - c), pb = abs(a - c), pc = abs(a + b - 2 * c);
-                    v += (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
-                } break;
-                default: return false;
-            }
-            cur[i] = (uint8_t)v;
+                    cur[i] = (uint8_t)(cur[i] + ((pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c)));
+                }
+                break;
+            default: return false;
         }
         memcpy(prev.data(), cur, rowbytes);
         uint8_t* out = line.data();
@@ -169,6 +179,11 @@ static bool decode_png(const std::vector<uint8_t>& d, std::vector<uint8_t>& img,
             const int v2 = (cur[idx / per] >> ((per - 1 - (int)(idx % per)) * depth)) & ((1 << depth) - 1);
             return ctype == 3 ? v2 : v2 * 255 / ((1 << depth) - 1);
         };
+        if (depth == 8 && ctype == 0) {
+            memcpy(out, cur, (size_t)w);  // 8-bit gray: the row is the output
+        } else if (depth == 8 && (ctype == 2 || ctype == 6)) {
+            for (int x = 0; x < w; x++) out[x] = rgb_to_gray(cur[(size_t)x * ch], cur[(size_t)x * ch + 1], cur[(size_t)x * ch + 2]);
+        } else
         for (int x = 0; x < w; x++) {
             if (ctype == 0 || ctype == 4) {
                 out[x] = (uint8_t)sample8((size_t)x * ch);
