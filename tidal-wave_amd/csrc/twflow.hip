@@ -280,7 +280,7 @@ struct ProfPair {
 
 // Optional roctx ranges (TW_ROCTX=1): one range per batch and per pyramid level on the submitting thread, so that a
 // rocprofv3 --marker-trace timeline shows which launches belong to which batch / level (SURVEY §5 "tracing"; the
-// reference only times the call, which `seconds` preserves).  libroctx64 is loaded on demand: no link dependency.
+// reference only times the call, which `seconds` preserves).  The roctx library is loaded on demand: no link dependency.
 struct Roctx {
     int (*push)(const char*) = nullptr;
     int (*pop)() = nullptr;
@@ -288,7 +288,10 @@ struct Roctx {
     {
         const char* ev = getenv("TW_ROCTX");
         if (!ev || !atoi(ev)) return;
-        void* h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+        // rocprofv3 (rocprofiler-sdk) listens to its own roctx library; roctracer's libroctx64 is the fallback
+        void* h = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("librocprofiler-sdk-roctx.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
         if (!h) h = dlopen("libroctx64.so.4", RTLD_NOW | RTLD_GLOBAL);
         if (!h) return;
         push = (int (*)(const char*))dlsym(h, "roctxRangePushA");
