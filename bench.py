@@ -2,31 +2,47 @@
 """bench.py — image-pairs/sec @1080p Farneback (default params) on N MI355X.
 
 Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 it is launched through
-torch.distributed.run, one rank per GPU.  One "step" = one pass of the hot path over one batch of
-BATCH synthetic 1920x1080 pairs that are already resident in HBM when the timed region starts; inside the timed
-region batch s+1 is submitted before the results of batch s are collected (a service's steady state: the engine
-keeps up to three batches outstanding), all K batches complete inside the region (BASELINE.json
-config "batch of 1080p pairs, 1xMI355X"; the single-pair latency of configs[1] is reported beside it).
-Pairs shard embarrassingly across ranks (weak scaling: every rank processes its own batch); there is no
-data-path collective — torch.distributed (RCCL) is used only for the barrier and the max-over-ranks of
-the elapsed time.
+torch.distributed.run, one rank per GPU.
 
-The JSON line also carries
-  roofline      dominant kernel (tw_blur_solve @ level 0): algorithmic bytes per launch / hipEvent-measured
-                average launch duration inside the timed region, vs the 8.0 TB/s HBM3E peak
+Two workloads, chosen EXPLICITLY with --mode and named in config.workload / config.mode (a 1 -> N curve is always
+one workload; VERDICT r2: `--gpus N` used to switch workloads silently between N = 1 and N > 1):
+
+  --mode resident (default; what the driver runs at every N)
+      One "step" = one pass of the hot path over one batch of BATCH synthetic 1920x1080 pairs per GPU that are already
+      resident in HBM when the timed region starts; inside the timed region engine batch s+1 is submitted before the
+      results of batch s are collected (a service's steady state: the engine keeps up to three batches outstanding),
+      all K steps complete inside the region.  Pairs shard embarrassingly across ranks (weak scaling: every rank
+      processes its own batches); there is no data-path collective — torch.distributed (RCCL) is used only for the
+      barrier and the max-over-ranks of the elapsed time.  Without torchrun, `--gpus N` (N > 1) starts the N ranks
+      itself (a torch.distributed.run child process) — the same workload, never another one.
+  --mode queue
+      BASELINE.json configs[3]'s shape: BATCH x N in-memory page-locked 1080p pairs through ONE twhost::Manager queue
+      with one consumer per GPU (tools/bench_queue.cpp; reference src/manager.cpp:55-59,68-78); uploads are inside the
+      timed region.  One process however many GPUs; under torchrun rank 0 drives all N devices and the other ranks
+      stay off the GPUs.  `--gpus 1 --mode queue` is this curve's own N = 1 point.
+
+Every line — both modes, every N — carries
+  roofline      dominant kernel (tw_blur_solve @ level 0): bytes the kernel as built moves per launch / hipEvent-
+                measured average launch duration inside the timed region (every rank's / consumer's engine brackets its
+                launches; the figure is rank 0's in resident mode and the all-consumer average in queue mode), vs the
+                8.0 TB/s HBM3E peak
   roofline_polyexp   the same for tw_polyexp @ level 0 (the kernel BASELINE.json grades)
-  cpu_baseline  the CPU oracle (a scalar port of OpenCV 2.4.9's algorithm; OpenCV itself is not
-                installable here) timed on this box's host cores on a bounded sample — rank 0, N=1 only
-  config3_host_pinned   BASELINE.json configs[2]: 256 x 1080p pairs handed over as page-locked HOST buffers
-                (tw_host_alloc), uploads on the engine's copy stream overlapped with the previous batch's kernels,
-                only the hits come back — wall-clock pairs/s, PCIe included (reference: src/opticalflow.cpp:100,115-116)
-  config5_4k    BASELINE.json configs[4] on one GPU: 3840x2160, pyrLevels 5, winSize 50, iters 5, resident in HBM
-  queue_sharded BASELINE.json configs[3]'s shape: in-memory pairs through ONE twhost::Manager queue with one
-                consumer per device (tools/bench_queue.cpp; reference src/manager.cpp:55-59,68-78)
-All three are measured outside the timed region, on rank 0 at N=1, and are never `value`.
-`python bench.py --gpus N` WITHOUT torchrun (no WORLD_SIZE in the environment) runs the queue-sharded driver on N
-devices of this box as the whole job: one process, N consumers on one queue, 256 pairs per device.
-The oracle is used here only as the cpu_baseline leg and to check one result; it is never the thing
+  cpu_baseline  the CPU oracle (a scalar port of OpenCV 2.4.9's algorithm; OpenCV itself is not installable here)
+                timed on this box's host cores on a bounded sample, by rank 0, outside the timed region (it does not
+                depend on N)
+At N = 1 in resident mode the line also carries, all measured outside the timed region and never `value`:
+  config3_host_pinned   BASELINE configs[2]: 2048 x 1080p pairs from page-locked HOST buffers in 128-pair engine
+                batches, uploads on the copy stream under the previous batch's kernels — pipeline fill and steady
+                state reported separately
+  config5_4k    BASELINE configs[4] on one GPU (3840x2160, pyrLevels 5, winSize 50, iters 5): 64 pairs of 4 distinct
+                images, with `roofline_cfg5` for its 51-tap window kernel from in-run events
+  queue_sharded the queue workload on one GPU (2048 pairs)
+  files_e2e     the service from FILES: PNG pairs in /dev/shm through host/index.js create() -> addon -> decode pool
+                -> engine (the decode-bound figure of SURVEY 8 f1)
+  polyexp_f32_variant   VERDICT r2 #3: the measurement variant of the polynomial expansion with float accumulators —
+                its roofline fraction, the max-abs flow error against the oracle and whether the vector lists survive
+  scan_fused_final      engine option TW_OPT_SCAN_FUSED_FINAL
+The oracle is used here only as the cpu_baseline leg and as the checker of those results; it is never the thing
 measured as `value`.
 """
 import argparse
@@ -47,6 +63,9 @@ import numpy as np  # noqa: E402
 W, H = 1920, 1080
 SPAN, THRESHOLD = 10, 5.0
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable copy rate)
+METRIC = "image-pairs/sec @1080p Farneback (default params), 1/2/4/8 MI355X"
+PARAMS_TEXT = ("default params (pyrScale 0.5, pyrLevels 3, winSize 30, iters 3, polyN 7, polySigma 1.5, Gaussian "
+               "window), span 10, threshold 5")
 
 
 def parse():
@@ -54,32 +73,42 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=256, help="1080p pairs per step per GPU (4 engine batches)")
+    ap.add_argument("--mode", choices=("resident", "queue"), default="resident",
+                    help="resident: pairs resident in HBM, one rank per GPU (the driver's workload); queue: in-memory "
+                         "host pairs through one manager queue with one consumer per GPU, uploads timed")
+    ap.add_argument("--batch", type=int, default=256, help="1080p pairs per step per GPU (2 engine batches)")
     ap.add_argument("--slots", type=int, default=128, help="pairs per engine batch (level-major schedule, one launch "
                                                             "per kernel and level for the whole batch)")
     ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic pairs cycled through")
+    ap.add_argument("--per-device", type=int, default=0,
+                    help="queue mode: consumers per GPU (0: 1, or what a rehearsal needs — see TW_BENCH_BACKEND)")
+    ap.add_argument("--port", type=int, default=0, help="rendezvous port when bench.py starts the ranks itself")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="no per-kernel hipEvents in the timed region")
-    ap.add_argument("--cpu-pairs", type=int, default=0, help="pairs in the CPU sample (0: one per thread)")
+    ap.add_argument("--cpu-pairs", type=int, default=0, help="pairs in the CPU sample (0: two per thread)")
     ap.add_argument("--no-extras", action="store_true",
-                    help="skip the untimed extra steps (kernel breakdown, scan-fused figure): a profiler trace then "
+                    help="skip the untimed extra steps (kernel breakdown, other configs): a profiler trace then "
                          "holds only the warm-up and the timed launches")
     return ap.parse_args()
 
 
-def cpu_baseline(pairs):
+# ---------------------------------------------------------------------------------------------------------------
+# the CPU leg
+# ---------------------------------------------------------------------------------------------------------------
+def cpu_baseline(pairs, njobs=0):
     """The reference's CPU driving pattern (src/manager.cpp:55-59: numThreads consumers on one queue, each
-    computing one pair at a time single-threaded) with the oracle standing in for OpenCV."""
+    computing one pair at a time single-threaded) with the oracle standing in for OpenCV.  Returns the bench-line
+    object, the scan results per job and the oracle flows of the distinct pairs (the checker of the extras)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as O
     O.build()
     O.lib()
-    cores = os.cpu_count() or 1
+    cores = len(os.sched_getaffinity(0)) or 1
     threads = min(cores, 16)
-    njobs = 2 * threads  # ~25-30 core-seconds of CPU work
+    njobs = njobs or 2 * threads  # ~25-30 core-seconds of CPU work
     jobs = list(range(njobs))
     lock = threading.Lock()
-    out = {}
+    out, flows = {}, {}
 
     def work():
         while True:
@@ -90,6 +119,8 @@ def cpu_baseline(pairs):
             a, b = pairs[j % len(pairs)]
             fx, fy = O.farneback(a, b)  # ctypes releases the GIL
             out[j] = O.span_scan(fx, fy, SPAN, THRESHOLD)
+            if j < len(pairs):
+                flows[j] = (fx, fy)
 
     # one pair on one thread first (the reference's per-call cost: OpenCV 2.4.9's Farneback is single-threaded)
     t1 = time.perf_counter()
@@ -102,16 +133,20 @@ def cpu_baseline(pairs):
     for t in th:
         t.join()
     dt = time.perf_counter() - t0
-    return {"value": njobs / dt, "unit": "pairs/s", "cores": threads, "kind": "port",
+    host_cores = os.cpu_count() or cores
+    return {"value": round(njobs / dt, 3), "unit": "pairs/s", "cores": threads, "kind": "port",
             "single_thread_pairs_per_s": round(1.0 / one, 3),
-            "host_cores": cores,
-            "extrapolated_all_host_cores_pairs_per_s": round(njobs / dt / threads * cores, 1),
+            "host_cores": host_cores,
+            "extrapolated_all_host_cores_pairs_per_s": round(njobs / dt / threads * host_cores, 1),
             "extrapolation_note": "measured rate per thread x host cores: a one-GPU lease of this pool is granted 16 "
                                   "of the host's cores, so the all-core figure is an extrapolation, not a measurement",
             "sample": "%d x 1920x1080 synthetic pairs pulled from one queue by %d threads (of %d host cores), %.1f s wall"
-                      % (njobs, threads, cores, dt)}, out
+                      % (njobs, threads, host_cores, dt)}, out, flows
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# the queue workload (tools/bench_queue.cpp)
+# ---------------------------------------------------------------------------------------------------------------
 QUEUE_BIN = os.path.join(ROOT, "tidal-wave_amd", "host", "build", "bench_queue")
 
 
@@ -121,9 +156,9 @@ def write_pgm(path, img):
         f.write(np.ascontiguousarray(img).tobytes())
 
 
-def queue_sharded(host_pairs, devices, pairs, per_device=1):
-    """BASELINE config 4's shape: `pairs` in-memory 1080p pairs through ONE twhost::Manager queue with one consumer
-    per device (tools/bench_queue.cpp — a child process: it creates its own engines).  Returns its JSON."""
+def queue_sharded(host_pairs, devices, pairs, per_device=1, batch=128):
+    """`pairs` in-memory 1080p pairs through ONE twhost::Manager queue with `per_device` consumers on each of
+    `devices` GPUs (tools/bench_queue.cpp — a child process: it creates its own engines).  Returns its JSON."""
     if not os.path.exists(QUEUE_BIN):
         return {"error": "tidal-wave_amd/host/build/bench_queue is not built"}
     tmp = tempfile.mkdtemp(prefix="twq_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
@@ -132,23 +167,124 @@ def queue_sharded(host_pairs, devices, pairs, per_device=1):
             write_pgm(os.path.join(tmp, "pair_%d_a.pgm" % i), a)
             write_pgm(os.path.join(tmp, "pair_%d_b.pgm" % i), b)
         r = subprocess.run([QUEUE_BIN, "--pgm-dir", tmp, "--pairs", str(pairs), "--devices", str(devices),
-                            "--per-device", str(per_device), "--batch", "128", "--warmup-batches", "2"],
+                            "--per-device", str(per_device), "--batch", str(batch), "--warmup-batches", "2"],
                            capture_output=True, text=True, timeout=900)
         lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
         if r.returncode != 0 or not lines:
             return {"error": "bench_queue rc %d: %s" % (r.returncode, (r.stderr or r.stdout)[-300:])}
         out = json.loads(lines[-1])
-        out["note"] = ("one process, one manager queue, %d consumer(s); page-locked in-memory pairs, uploads included; "
-                       "tools/bench_queue.cpp" % out.get("consumers", 0))
+        out["note"] = ("one process, one manager queue, %d consumer(s), every consumer warm and its engine created "
+                       "before the clock starts; page-locked in-memory pairs, uploads included; tools/bench_queue.cpp"
+                       % out.get("consumers", 0))
         return out
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-def config3_host_pinned(twflow, host_pairs, device, slots=64, total=256):
-    """BASELINE configs[2]: `total` 1080p pairs from page-locked host buffers on one GPU; the upload of batch j+1
-    runs on the engine's copy stream under the kernels of batch j; only the hits come back.  Wall clock.  An engine
-    of its own with 64-pair batches: four batches, so that three of them run with an upload beside them."""
+def load_traffic():
+    tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    if os.path.exists(tpath):
+        try:
+            return json.load(open(tpath))
+        except Exception:
+            pass
+    return {}
+
+
+def roofline_obj(name, ms, launches, bytes_total, pairs_per_launch, traffic, chunk=None, note=None):
+    """`bytes_total` moved by `launches` bracketed launches that took `ms` in total."""
+    if not launches or ms <= 0:
+        return None
+    gbs = bytes_total / (ms * 1e-3) / 1e9
+    tr = traffic.get(name)
+    tr_bytes = tr_pairs = None
+    if isinstance(tr, dict) and tr.get("pairs_per_launch"):
+        # the PMC passes measured launches of tr_pairs pairs; traffic is linear in the pairs of a launch
+        tr_pairs = tr["pairs_per_launch"]
+        tr_bytes = round(tr["bytes_per_launch"] * pairs_per_launch / tr_pairs)
+    return {"kernel": name + " @level0 (1920x1080)", "bound": "hbm", "achieved": round(gbs, 1),
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+            "traffic": tr_bytes, "traffic_pairs_per_launch": tr_pairs,
+            "traffic_source": "profiles/traffic_latest.json (static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                              "passes of an earlier run of this command, not a live counter; measured on launches "
+                              "of traffic_pairs_per_launch pairs and scaled to this run's pairs per launch)",
+            "bytes_model": "what the kernel as built must move per launch (blur+solve: 80 B/px for a launch "
+                           "fused with the matrix refresh, 28 B/px for the last one; polyexp 24 B/px)",
+            "algorithmic_bytes_per_launch": bytes_total / launches,
+            "avg_launch_us": round(ms / launches * 1e3, 2), "launches": launches,
+            "pairs_per_launch": round(pairs_per_launch, 2), "level_chunk": chunk,
+            "note": note or "hipEvent-bracketed launches inside the timed region (single stream); achieved = "
+                            "bytes of all bracketed launches / their summed duration"}
+
+
+def queue_mode(args, rehearse):
+    """The queue workload as the whole job on args.gpus devices."""
+    import synth
+    import twflow
+    ndev = twflow.device_count()
+    if ndev < 1:
+        raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
+    n = args.gpus
+    devices, per_dev = min(n, ndev), max(1, args.per_device)
+    if ndev < n:
+        if not rehearse:
+            raise SystemExit("bench.py --mode queue --gpus %d: the box has %d device(s) (TW_BENCH_BACKEND=gloo rehearses "
+                             "the N-consumer shape on fewer cards)" % (n, ndev))
+        per_dev = max(per_dev, (n + ndev - 1) // ndev)
+    host_pairs = [synth.make_pair(i, H, W) for i in range(args.distinct)]
+    total = args.batch * n * max(1, args.steps // 5)  # 2 x 256 pairs per GPU at the default K = 10
+    with twflow.Engine(0, twflow.default_params(), slots=1) as e:  # the byte model lives in the library
+        bytes_pair = e.algorithmic_bytes_pair(W, H, SPAN)
+        by = {twflow.K_BLUR_SOLVE: e.algorithmic_bytes(twflow.K_BLUR_SOLVE, 0, W, H) * 3,
+              twflow.K_POLYEXP: e.algorithmic_bytes(twflow.K_POLYEXP, 0, W, H)}
+    out = queue_sharded(host_pairs, devices, total, per_dev, batch=args.slots)
+    if "error" in out:
+        raise SystemExit("queue-sharded run failed: " + out["error"])
+    traffic = load_traffic()
+    pc = out.get("per_consumer", [])
+    pairs_prof = sum(c["pairs"] for c in pc)
+
+    def roof(kc, key):
+        ms = sum(c["%s_l0_ms" % key] for c in pc)
+        ln = sum(c["%s_l0_launches" % key] for c in pc)
+        per_pair_launches = 3 if kc == twflow.K_BLUR_SOLVE else 1
+        return roofline_obj(twflow.KERNEL_NAMES[kc], ms, ln, by[kc] * pairs_prof,
+                            per_pair_launches * pairs_prof / max(ln, 1), traffic,
+                            note="hipEvent-bracketed launches of every consumer's engine inside the timed region; "
+                                 "achieved = bytes of all bracketed launches / their summed duration (the average "
+                                 "launch on the average device)")
+
+    line = {
+        "metric": METRIC, "value": out["pairs_per_s"], "unit": "pairs/s", "n_gpus": n, "steps": 1, "warmup": 2,
+        "ms_per_step": round(out["seconds"] * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "queue: %d x 1920x1080 u8 gray pairs (%d per GPU) from page-locked host memory through "
+                               "one manager queue with one consumer per GPU (BASELINE config 4's shape), %s; uploads "
+                               "inside the timed region" % (out["pairs"], out["pairs"] // n, PARAMS_TEXT),
+                   "mode": "queue", "batch_per_gpu": out["pairs"] // n, "engine_batch": args.slots,
+                   "parallelism": "one process, %d consumers on one request queue, no collective" % out["consumers"],
+                   "rehearsal": None if ndev >= n else "%d consumers time-share %d device(s): a rehearsal of the N-device "
+                                                      "shape, not a scaling point" % (out["consumers"], ndev)},
+        "pair_roofline": {"algorithmic_bytes_per_pair": bytes_pair,
+                          "frac_of_8TBps": round(bytes_pair * out["pairs_per_s"] / n / 1e9 / HBM_PEAK_GBS, 4)},
+        "queue_sharded": out,
+        "roofline": roof(twflow.K_BLUR_SOLVE, "blur"), "roofline_polyexp": roof(twflow.K_POLYEXP, "polyexp"),
+    }
+    if args.no_cpu_baseline:
+        line["cpu_baseline"] = None
+    else:
+        line["cpu_baseline"], _, _ = cpu_baseline(host_pairs, args.cpu_pairs)
+    print(json.dumps(line), flush=True)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the other BASELINE configs (resident mode, N = 1, outside the timed region)
+# ---------------------------------------------------------------------------------------------------------------
+def config3_host_pinned(twflow, host_pairs, device, slots=128, total=2048):
+    """BASELINE configs[2]: `total` 1080p pairs from page-locked host buffers on one GPU in `slots`-pair engine
+    batches; the upload of batch j+1 runs on the engine's copy stream under the kernels of batch j; only the hits
+    come back.  Wall clock.  Pipeline fill (until the first batch has answered: its upload is overlapped with
+    nothing) and steady state (everything after) are reported separately."""
     with twflow.Engine(device, twflow.default_params(), slots=slots) as eng:
         pinned = []
         for a, b in host_pairs:
@@ -156,7 +292,7 @@ def config3_host_pinned(twflow, host_pairs, device, slots=64, total=256):
             pa[:] = a
             pb[:] = b
             pinned.append((pa, pb))
-        nb = max(1, total // slots)
+        nb = max(2, total // slots)
 
         def submit_batch(k):
             return [eng.submit(*pinned[(k * slots + j) % len(pinned)]) for j in range(slots)]
@@ -166,92 +302,196 @@ def config3_host_pinned(twflow, host_pairs, device, slots=64, total=256):
 
         drain(submit_batch(0))  # warm-up: the batch contexts' device image regions
         t0 = time.perf_counter()
-        inflight = [submit_batch(0)] + ([submit_batch(1)] if nb > 1 else [])
+        inflight = [submit_batch(0), submit_batch(1)]
         hits = 0
+        t_first = None
         for k in range(2, nb + 2):
             hits += drain(inflight.pop(0))
+            if t_first is None:
+                t_first = time.perf_counter()
             if k < nb:
                 inflight.append(submit_batch(k))
-        dt = time.perf_counter() - t0
+        t_end = time.perf_counter()
     n = slots * nb
-    return {"pairs_per_s": round(n / dt, 1), "pairs": n, "ms_per_pair": round(dt / n * 1e3, 4),
+    fill, steady = t_first - t0, t_end - t_first
+    return {"pairs_per_s": round(n / (t_end - t0), 1), "pairs": n, "engine_batch": slots,
+            "steady_state_pairs_per_s": round((n - slots) / steady, 1),
+            "fill_ms": round(fill * 1e3, 2), "steady_ms_per_batch": round(steady / (nb - 1) * 1e3, 3),
+            "ms_per_pair": round((t_end - t0) / n * 1e3, 4),
             "h2d_MB_per_pair": round(2 * W * H / 1e6, 2), "flagged_vectors": hits,
             "note": "page-locked caller buffers (tw_host_alloc), H2D on the copy stream overlapped with the previous "
-                    "batch's kernels, D2H = hit records only; wall clock over %d engine batches of %d" % (nb, slots)}
+                    "batch's kernels, D2H = hit records only; wall clock over %d engine batches of %d; fill = until "
+                    "the first batch answered, steady state = the %d batches after it" % (nb, slots, nb - 1)}
 
 
-def config5_4k(twflow, synth, batch=8, steps=2):
+def config5_4k(twflow, synth, device, batch=16, steps=4, distinct=4):
     """BASELINE configs[4] on ONE GPU: 3840x2160, pyrLevels 5, winSize 50, iters 5; pairs resident in HBM."""
     W5, H5 = 3840, 2160
     kw = dict(pyrLevels=5, winSize=50, pyrIterations=5)
-    with twflow.Engine(0 if "LOCAL_RANK" not in os.environ else int(os.environ["LOCAL_RANK"]),
-                       twflow.default_params(**kw), slots=batch) as e:
-        a, b = synth.make_pair(1, H5, W5)
-        da, db = e.upload(a), e.upload(b)
+    with twflow.Engine(device, twflow.default_params(**kw), slots=batch) as e:
+        dev = []
+        for i in range(distinct):
+            a, b = synth.make_pair(i, H5, W5)
+            dev.append((e.upload(a), e.upload(b)))
 
         def step():
-            tickets = [e.submit_dev(da, db, W5, H5, W5, SPAN, THRESHOLD) for _ in range(batch)]
+            tickets = [e.submit_dev(dev[i % distinct][0], dev[i % distinct][1], W5, H5, W5, SPAN, THRESHOLD)
+                       for i in range(batch)]
             return sum(e.wait_count(t)[0] for t in tickets)
 
         step()
+        e.prof_select(twflow.K_BLUR_SOLVE, 0)
         t0 = time.perf_counter()
         flagged = 0
         for _ in range(steps):
             flagged += step()
         dt = time.perf_counter() - t0
+        ms, nl = e.prof_read(twflow.K_BLUR_SOLVE)
+        e.prof_select(-1, -2)
         per_pair = e.algorithmic_bytes_pair(W5, H5, SPAN)
+        it = kw["pyrIterations"]
+        by = e.algorithmic_bytes(twflow.K_BLUR_SOLVE, 0, W5, H5) * it * batch * steps
         v = batch * steps / dt
-        return {"pairs_per_s": round(v, 2), "pairs": batch * steps, "ms_per_pair": round(1e3 / v, 3),
+        roof = None
+        if nl:
+            gbs = by / (ms * 1e-3) / 1e9
+            roof = {"kernel": "tw_blur_solve (51-tap window, winSize 50) @level0 (3840x2160)", "bound": "hbm",
+                    "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                    "traffic": None, "avg_launch_us": round(ms / nl * 1e3, 1), "launches": nl,
+                    "pairs_per_launch": round(it * batch * steps / nl, 2),
+                    "algorithmic_bytes_per_launch": by / nl,
+                    "note": "hipEvent-bracketed level-0 launches of this run; bytes as built (80 B/px fused with the "
+                            "matrix refresh, 28 B/px the last of the 5 iterations)"}
+        return {"pairs_per_s": round(v, 2), "pairs": batch * steps, "distinct_pairs": distinct, "engine_batch": batch,
+                "ms_per_pair": round(1e3 / v, 3),
                 "algorithmic_MB_per_pair": round(per_pair / 1e6, 1), "frac_of_8TBps": round(v * per_pair / 8e12, 4),
-                "levels": e.num_levels(W5, H5) + 1, "flagged_vectors": flagged,
-                "note": "3840x2160, pyrLevels 5, winSize 50, iters 5, one GPU, one distinct synthetic pair resident in HBM"}
+                "levels": e.num_levels(W5, H5) + 1, "flagged_vectors": flagged, "roofline_cfg5": roof,
+                "note": "3840x2160, pyrLevels 5, winSize 50, iters 5, one GPU, %d distinct synthetic pairs resident "
+                        "in HBM, %d steps of %d pairs" % (distinct, steps, batch)}
 
 
-def queue_mode(args):
-    """`python bench.py --gpus N` without torchrun: the whole job is the queue-sharded driver on N devices."""
-    import synth
-    host_pairs = [synth.make_pair(i, H, W) for i in range(args.distinct)]
-    per_gpu = args.batch
-    out = queue_sharded(host_pairs, args.gpus, per_gpu * args.gpus)
-    if "error" in out:
-        raise SystemExit("queue-sharded run failed: " + out["error"])
-    bytes_pair = 991771776.0  # SURVEY.md 8(d): 1080p, default parameters (tw_algorithmic_bytes_pair)
-    n = out["devices"]
-    line = {
-        "metric": "image-pairs/sec @1080p Farneback (default params), 1/2/4/8 MI355X",
-        "value": out["pairs_per_s"], "unit": "pairs/s", "n_gpus": n, "steps": 1, "warmup": 2,
-        "ms_per_step": round(out["seconds"] * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "%d x 1920x1080 u8 gray pairs (%d per GPU) from page-locked host memory through one "
-                               "manager queue with one consumer per GPU (BASELINE config 4's shape), default params, "
-                               "span 10, threshold 5; uploads inside the timed region" % (out["pairs"], per_gpu),
-                   "parallelism": "one process, %d consumers on one request queue, no collective" % out["consumers"]},
-        "pair_roofline": {"algorithmic_bytes_per_pair": bytes_pair,
-                          "frac_of_8TBps": round(bytes_pair * out["pairs_per_s"] / n / 1e9 / HBM_PEAK_GBS, 4)},
-        "queue_sharded": out, "roofline": None, "cpu_baseline": None,
-    }
-    print(json.dumps(line), flush=True)
+def files_e2e(host_pairs, pairs=256, threads=8):
+    """The service from FILES: `pairs` 1080p PNG pairs (the distinct synthetic pairs, hard-linked) in
+    /dev/shm through host/index.js create() -> N-API addon -> decode pool -> engine; pairs/s on node's clock between
+    create() and 'finish'."""
+    host = os.path.join(ROOT, "tidal-wave_amd", "host")
+    if shutil.which("node") is None or not os.path.exists(os.path.join(host, "build", "Release", "tidalwave.node")):
+        return {"error": "node or the addon is missing"}
+    from PIL import Image
+    d = tempfile.mkdtemp(prefix="twe2e_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        os.makedirs(os.path.join(d, "expected", "s"))
+        os.makedirs(os.path.join(d, "target", "s"))
+        nd = len(host_pairs)
+        size = 0
+        for i in range(pairs):
+            pe = os.path.join(d, "expected", "s", "p%04d.png" % i)
+            pt = os.path.join(d, "target", "s", "p%04d.png" % i)
+            if i < nd:
+                Image.fromarray(host_pairs[i][0]).save(pe, compress_level=3)
+                Image.fromarray(host_pairs[i][1]).save(pt, compress_level=3)
+                size += os.path.getsize(pe) + os.path.getsize(pt)
+            else:  # hard links: the decoder reads and inflates every file all the same
+                os.link(os.path.join(d, "expected", "s", "p%04d.png" % (i % nd)), pe)
+                os.link(os.path.join(d, "target", "s", "p%04d.png" % (i % nd)), pt)
+        js = ("var T=require('./index'); var t0=Date.now(); var n=0, e=0;"
+              "var t=T.create(process.argv[1],{expectDir:process.argv[2], numThreads:%d});"
+              "t.on('data',function(){n++}); t.on('error',function(){e++});"
+              "t.on('finish',function(r){console.log(JSON.stringify({report:r, data:n, errors:e, ms:Date.now()-t0}))});"
+              % threads)
+        r = subprocess.run(["node", "-e", js, os.path.join(d, "target"), os.path.join(d, "expected")], cwd=host,
+                           capture_output=True, text=True, timeout=600)
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode != 0 or not lines:
+            return {"error": "node rc %d: %s" % (r.returncode, (r.stderr or r.stdout)[-300:])}
+        out = json.loads(lines[-1])
+        dec = os.environ.get("TW_DECODE_THREADS") or "auto (host cores / consumers, at most 16)"
+        return {"pairs_per_s": round(out["data"] / (out["ms"] / 1e3), 1), "pairs": out["data"], "errors": out["errors"],
+                "ms": out["ms"], "png_MB_per_pair": round(size / nd / 1e6, 2), "decode_threads": dec,
+                "host_cores_available": len(os.sched_getaffinity(0)),
+                "note": "1920x1080 8-bit gray PNG files (zlib level 3) in /dev/shm through host/index.js create() -> "
+                        "addon -> decode pool -> libtwflow.so; decode + upload + flow + scan + event delivery"}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def polyexp_f32_variant(twflow, device, host_pairs, flows, scans):
+    """the float-accumulator measurement variant (TW_OPT_POLYEXP_F32): roofline fraction of isolated
+    level-0 launches (exact kernel beside it, same loop) and what it does to the flow and to the vector lists."""
+    n_img = 64
+    out = {}
+    with twflow.Engine(device, twflow.default_params(), slots=n_img) as e:
+        by = e.algorithmic_bytes(twflow.K_POLYEXP, 0, W, H) / 2 * n_img
+        for name, opt in (("exact_f64", 0), ("f32", 1)):
+            e.set_option(twflow.OPT_POLYEXP_F32, opt)
+            us = min(e.bench_stage(twflow.K_POLYEXP, W, H, 0, n_img // 2, 20, 0) for _ in range(2))
+            out["frac" if opt else "frac_exact_same_loop"] = round(by / us / 1e3 / HBM_PEAK_GBS, 4)
+            out["us_per_image" if opt else "us_per_image_exact_same_loop"] = round(us / n_img, 2)
+        e.set_option(twflow.OPT_POLYEXP_F32, 0)
+    err, ident = 0.0, True
+    with twflow.Engine(device, twflow.default_params(), slots=1) as e:
+        e.set_option(twflow.OPT_POLYEXP_F32, 1)
+        for j, (wx, wy) in sorted(flows.items()):
+            a, b = host_pairs[j]
+            fx, fy, _ = e.calculate_internal(a, b)
+            err = max(err, float(np.abs(fx - wx).max()), float(np.abs(fy - wy).max()))
+            ident = ident and (e.diff(a, b, SPAN, THRESHOLD)["vector"] == scans[j])
+    out.update({"max_abs_flow_err": err, "vectors_identical": bool(ident), "pairs_checked": len(flows),
+                "note": "isolated back-to-back launches of 64 images (tw_bench_stage; the same loop runs the exact "
+                        "kernel slower than the bench's kernel mix does); flow error of the variant against the CPU "
+                        "oracle on this run's distinct synthetic pairs (the exact engine's error is 0); "
+                        "profiles/r03_polyexp_f32.md has the golden pair and a flat-region stress image as well"})
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def launch_ranks(args):
+    """`python bench.py --gpus N` (N > 1) without torchrun: start the N ranks of the resident workload as a child
+    torch.distributed.run (this process has not touched the GPU) and exit with its code."""
+    port = args.port or (29500 + os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
 
 
 def main():
     args = parse()
-    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-        return queue_mode(args)
-    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != args.gpus:
+    backend = os.environ.get("TW_BENCH_BACKEND", "nccl")  # gloo: several ranks / consumers rehearse on one card
+    in_launcher = "WORLD_SIZE" in os.environ
+    if in_launcher and int(os.environ["WORLD_SIZE"]) != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%s: launch one rank per GPU (torch.distributed.run "
-                         "--nproc-per-node %d), or run without torchrun for the queue-sharded driver"
-                         % (args.gpus, os.environ["WORLD_SIZE"], args.gpus))
+                         "--nproc-per-node %d), or run without torchrun" % (args.gpus, os.environ["WORLD_SIZE"], args.gpus))
     rank = int(os.environ.get("RANK", "0"))
+    if not os.path.exists(os.path.join(ROOT, "tidal-wave_amd", "libtwflow.so")) and int(os.environ.get("LOCAL_RANK", "0")) == 0:
+        import __graft_entry__  # fresh checkout: the binaries are git-ignored (building is not a fallback)
+        __graft_entry__.build()
+    if args.mode == "queue":
+        # one process drives every device: under a launcher rank 0 does, the other ranks stay off the GPUs
+        if rank == 0:
+            queue_mode(args, rehearse=(backend == "gloo"))
+        return 0
+    if not in_launcher and args.gpus > 1:
+        return launch_ranks(args)
+
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     dist = None
-    # one process per GPU; TW_BENCH_BACKEND=gloo lets two ranks share one card for a rehearsal on a 1-GPU box
-    backend = os.environ.get("TW_BENCH_BACKEND", "nccl")
     ndev = torch.cuda.device_count()
     if ndev < 1:
         raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
+    if ndev < world and backend != "gloo":
+        raise SystemExit("bench.py: %d ranks but %d device(s) (TW_BENCH_BACKEND=gloo rehearses on fewer cards)" % (world, ndev))
     dev_index = local_rank % ndev
+    import shard
+    import twflow
+    # one process per GPU, placed on the GPU's NUMA node before anything page-locked is allocated
+    try:
+        bus = twflow.device_pci_bus_id(dev_index)
+    except Exception:
+        bus = ""
+    numa_node, prev_affinity = shard.bind_to_device_node(bus) if bus else (-1, os.sched_getaffinity(0))
     torch.cuda.set_device(dev_index)
     if world > 1:
         import torch.distributed as dist
@@ -259,14 +499,8 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
         else:
             dist.init_process_group(backend=backend)
-
-    if not os.path.exists(os.path.join(ROOT, "tidal-wave_amd", "libtwflow.so")) and local_rank == 0:
-        import __graft_entry__  # fresh checkout: the binaries are git-ignored (building is not a fallback)
-        __graft_entry__.build()
-    if dist is not None:
         dist.barrier()
     import synth
-    import twflow
 
     if twflow.device_count() < 1:
         raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
@@ -320,7 +554,7 @@ def main():
     # single-pair latency (configs[1]) and a result check before timing
     res0 = eng.diff(host_pairs[0][0], host_pairs[0][1], SPAN, THRESHOLD)
     lat = []
-    for _ in range(5):
+    for _ in range(7):
         r = eng.wait(eng.submit_dev(dev_pairs[0][0], dev_pairs[0][1], W, H, W, SPAN, THRESHOLD))
         lat.append(r["time"])
     assert r["vector"] == res0["vector"]
@@ -335,7 +569,6 @@ def main():
     run_steps(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
-    import shard
     elapsed, (flagged_total, pairs_total) = shard.reduce_max_sum(
         dist, torch.device("cuda", dev_index) if backend == "nccl" else torch.device("cpu"), elapsed,
         [flagged[0], args.batch * args.steps])
@@ -400,13 +633,7 @@ def main():
             del src, dst
         except Exception:
             copy_gbs = None
-        traffic = {}
-        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath))
-            except Exception:
-                traffic = {}
+        traffic = load_traffic()
 
         def roof(kc):
             if kc not in prof or prof[kc][1] == 0:
@@ -418,42 +645,22 @@ def main():
             per_pair_launches = 3 if kc == twflow.K_BLUR_SOLVE else 1
             pairs_mine = args.batch * args.steps
             bytes_total = eng.algorithmic_bytes(kc, 0, W, H) * per_pair_launches * pairs_mine
-            gbs = bytes_total / (ms * 1e-3) / 1e9
-            name = twflow.KERNEL_NAMES[kc]
-            chunk = eng.level_chunk(W, H, 0)
-            tr = traffic.get(name)
-            ppl = per_pair_launches * pairs_mine / n  # pairs per launch in this run
-            tr_bytes = tr_pairs = None
-            if isinstance(tr, dict) and tr.get("pairs_per_launch"):
-                # the PMC passes measured launches of tr_pairs pairs; traffic is linear in the pairs of a launch
-                tr_pairs = tr["pairs_per_launch"]
-                tr_bytes = round(tr["bytes_per_launch"] * ppl / tr_pairs)
-            return {"kernel": name + " @level0 (1920x1080)", "bound": "hbm", "achieved": round(gbs, 1),
-                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-                    "traffic": tr_bytes,
-                    "traffic_pairs_per_launch": tr_pairs,
-                    "traffic_source": "profiles/traffic_latest.json (static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
-                                      "passes of an earlier run of this command, not a live counter; measured on launches "
-                                      "of traffic_pairs_per_launch pairs and scaled to this run's pairs per launch)",
-                    "bytes_model": "what the kernel as built must move per launch (blur+solve: 80 B/px for a launch "
-                                   "fused with the matrix refresh, 28 B/px for the last one; polyexp 24 B/px)",
-                    "algorithmic_bytes_per_launch": bytes_total / n,
-                    "avg_launch_us": round(ms / n * 1e3, 2), "launches": n,
-                    "pairs_per_launch": round(per_pair_launches * pairs_mine / n, 2), "level_chunk": chunk,
-                    "note": "hipEvent-bracketed launches inside the timed region (single stream); achieved = "
-                            "algorithmic bytes of all bracketed launches / their summed duration"}
+            return roofline_obj(twflow.KERNEL_NAMES[kc], ms, n, bytes_total, per_pair_launches * pairs_mine / n,
+                                traffic, chunk=eng.level_chunk(W, H, 0))
 
         line = {
-            "metric": "image-pairs/sec @1080p Farneback (default params), 1/2/4/8 MI355X",
+            "metric": METRIC,
             "value": round(value, 2), "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "batch of %d x 1920x1080 u8 gray pairs per GPU per step, resident in HBM, "
-                                   "default params (pyrScale 0.5, pyrLevels 3, winSize 30, iters 3, polyN 7, "
-                                   "polySigma 1.5, Gaussian window), span 10, threshold 5" % args.batch,
-                       "batch_per_gpu": args.batch, "engine_batch": args.slots,
-                       "parallelism": "pairs sharded over %d GPU(s), no collective" % world,
+            "config": {"workload": "resident: batch of %d x 1920x1080 u8 gray pairs per GPU per step, resident in HBM, "
+                                   "%s" % (args.batch, PARAMS_TEXT),
+                       "mode": "resident", "batch_per_gpu": args.batch, "engine_batch": args.slots,
+                       "parallelism": "pairs sharded over %d GPU(s), one rank per GPU, no collective" % world,
+                       "numa_node_rank0": numa_node, "backend": backend if world > 1 else None,
+                       "rehearsal": None if ndev >= world else "%d ranks time-share %d device(s): a rehearsal of the "
+                                                              "N-device shape, not a scaling point" % (world, ndev),
                        "single_pair_latency_ms": round(float(np.median(lat)) * 1e3, 4)},
             "measured_copy_GBps": copy_gbs,
             "pair_roofline": {"algorithmic_bytes_per_pair": bytes_pair,
@@ -475,30 +682,41 @@ def main():
             "roofline_polyexp": roof(twflow.K_POLYEXP),
             "flagged_vectors": flagged_total,
         }
-        if world == 1 and not args.no_extras:
+        extras = world == 1 and not args.no_extras
+        if extras:
             # the other BASELINE configs, outside the timed region (never `value`)
             for key, fn in (("config3_host_pinned", lambda: config3_host_pinned(twflow, host_pairs, dev_index)),
-                            ("config5_4k", lambda: config5_4k(twflow, synth)),
-                            ("queue_sharded", lambda: queue_sharded(host_pairs, 1, 2048))):
+                            ("config5_4k", lambda: config5_4k(twflow, synth, dev_index)),
+                            ("queue_sharded", lambda: queue_sharded(host_pairs, 1, 2048)),
+                            ("files_e2e", lambda: files_e2e(host_pairs))):
                 try:
                     line[key] = fn()
                 except Exception as ex:  # an extra must never cost the headline line
                     line[key] = {"error": "%s: %s" % (type(ex).__name__, ex)}
-        if world == 1 and not args.no_cpu_baseline:
-            cb, cpu_out = cpu_baseline(host_pairs)
+        if args.no_cpu_baseline:
+            line["cpu_baseline"] = None
+        else:
+            # rank 0, once, at every N (it does not depend on N); on all the CPUs this process was given, not only
+            # those of the GPU's node
+            os.sched_setaffinity(0, prev_affinity)
+            cb, cpu_out, flows = cpu_baseline(host_pairs, args.cpu_pairs)
             line["cpu_baseline"] = cb
             # the GPU answer for pair 0 equals the oracle's (vector list, bit for bit)
             line["cpu_baseline"]["gpu_matches_oracle_on_pair0"] = bool(cpu_out.get(0) == res0["vector"]) \
                 if 0 in cpu_out else None
-        else:
-            line["cpu_baseline"] = None
+            if extras:
+                try:
+                    line["polyexp_f32_variant"] = polyexp_f32_variant(twflow, dev_index, host_pairs, flows, cpu_out)
+                except Exception as ex:
+                    line["polyexp_f32_variant"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
         print(json.dumps(line), flush=True)
 
     eng.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

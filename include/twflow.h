@@ -67,9 +67,19 @@ typedef int64_t tw_ticket;
 /* Defaults of Broker::createInstance, /root/reference/src/broker.cpp:111-117. */
 void tw_default_params(tw_params* p);
 
+/* 1 for a `make VARIANTS=1` build (tidal-wave_amd/libtwflow_variants.so: the default library plus the measured-slower
+ * A/B kernels behind TW_BLUR_VARIANT / TW_POLY_VARIANT / TW_BLUR_SMALL / TW_UPD_NY — tests and tools only), 0 for the
+ * product library, which carries only kernels a launch can reach with no environment variable set. */
+int tw_has_variants(void);
+
 /* cv::gpu::getCudaEnabledDeviceCount() of src/consumer.cpp:19-20: number of usable HIP devices
  * (0 when there is none or the runtime cannot initialise). */
 int tw_device_count(void);
+
+/* PCI bus id of a device ("0000:c1:00.0", NUL-terminated, cap >= 16) — lets the host layer place consumer i and its
+ * page-locked buffers on the NUMA node of GPU i (SURVEY.md 8(e) "scaling risks"; the reference's consumer i <-> device i
+ * mapping is src/consumer.cpp:18-24).  TW_E_DEVICE if the device does not exist. */
+tw_status tw_device_pci_bus_id(int device, char* buf, int cap);
 
 /* new OpticalFlowByGPU() + cv::gpu::setDevice(id), src/consumer.cpp:21-30.
  * `slots` = image pairs per batch (>= 1); up to three batches may be outstanding.  Parameters are fixed per engine like Consumer::parameter (src/consumer.cpp:97). */
@@ -123,18 +133,27 @@ tw_status tw_dev_upload(tw_engine* e, void* dptr, const void* host, size_t bytes
  *   window average + solve of level 0 only at the span-grid points the scan reads.  Status and vectors are
  *   bit-identical; the dense flow field of that last iteration is simply never materialised (tw_flow_u8 always
  *   computes the whole field).  Off by default because the reference's path — and bench.py's headline — produce
- *   the full field. */
-enum { TW_OPT_SCAN_FUSED_FINAL = 1 };
+ *   the full field.
+ * TW_OPT_POLYEXP_F32 (default 0): MEASUREMENT variant of the polynomial expansion with float instead of double
+ *   horizontal accumulators (polyN 5 or 7; what OpenCV's CUDA module does).  NOT bit-identical to the CPU reference;
+ *   exists so that "what would the kernel cost without its f64 half, and what would it do to the flow" is a number
+ *   (bench.py `polyexp_f32_variant`, profiles/r03_polyexp_f32.md).  Never on by default, never bench.py's `value`. */
+enum { TW_OPT_SCAN_FUSED_FINAL = 1, TW_OPT_POLYEXP_F32 = 2 };
 tw_status tw_set_option(tw_engine* e, int option, int value);
 
-/* Page-locked host memory.  Images handed to tw_submit_u8 from such memory (or from memory the caller
- * registered with hipHostRegister) are DMA-ed to the device straight from the caller's buffer on the engine's
+/* Page-locked host memory.  Images handed to tw_submit_u8 from a block tw_host_alloc returned (or that the caller
+ * page-locked through tw_host_register) are DMA-ed to the device straight from the caller's buffer on the engine's
  * copy stream — no staging copy — and must therefore stay unchanged until tw_wait() of the ticket returns.
- * Ordinary (pageable) memory is staged through the engine's own pinned buffers and may be reused as soon as
- * tw_submit_u8 returns.  Either way the upload of batch j+1 overlaps the kernels of batch j (BASELINE config 3:
- * "pinned H2D/D2H overlapped on a side stream"). */
+ * Any other memory is treated as pageable: it is staged through the engine's own pinned buffers and may be reused as
+ * soon as tw_submit_u8 returns (memory page-locked behind the library's back, e.g. by a direct hipHostRegister, is
+ * staged too — correct, one memcpy slower).  The blocks are usable by the engines of every device and by every
+ * thread (the table of them is process-wide).  Either way the upload of batch j+1 overlaps the kernels of batch j
+ * (BASELINE config 3: "pinned H2D/D2H overlapped on a side stream"). */
 tw_status tw_host_alloc(tw_engine* e, size_t bytes, void** hptr);
 tw_status tw_host_free(tw_engine* e, void* hptr);
+/* Page-lock / release memory the caller owns (hipHostRegister / hipHostUnregister + the table above). */
+tw_status tw_host_register(tw_engine* e, void* hptr, size_t bytes);
+tw_status tw_host_unregister(tw_engine* e, void* hptr);
 
 /* ---- instrumentation (bench.py / tests) ---------------------------------------------------------- */
 

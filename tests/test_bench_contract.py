@@ -1,9 +1,13 @@
 """The bench line's contract (driver + judge read it): the committed line of this round carries every required key,
-and bench.py's argument handling refuses a --gpus that disagrees with the launcher.  CPU only."""
+bench.py's argument handling refuses a --gpus that disagrees with the launcher and never switches workloads with N
+(CPU), and — on the GPU box — both workloads rehearsed with two ranks / two consumers on one card print a line that
+carries `roofline` and `cpu_baseline`."""
 import json
 import os
 import subprocess
 import sys
+
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -40,3 +44,60 @@ def test_gpus_flag_must_match_the_launcher():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], capture_output=True, text=True,
                        env=env, timeout=120)
     assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stderr + r.stdout)
+
+
+def test_plain_gpus_n_stays_on_the_resident_workload():
+    """`python bench.py --gpus 2` without torchrun used to turn into the queue workload: it now starts
+    the two ranks of the SAME resident workload itself.  Without a GPU those ranks must fail loudly (no CPU fallback),
+    and nothing may print a bench line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["TW_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=600)
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by the rehearsal test")
+    assert r.returncode != 0
+    assert "needs a HIP device" in (r.stderr + r.stdout)
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_mode_flag_is_explicit():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "sideways"], capture_output=True,
+                       text=True, timeout=120)
+    assert r.returncode != 0 and "invalid choice" in r.stderr
+
+
+def _line(r):
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.stdout[-1500:], r.stderr[-3000:])
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["resident", "queue"])
+def test_two_gpu_shape_rehearsed_on_one_card_is_a_creditable_line(mode):
+    """--gpus 2 on a one-GPU box (TW_BENCH_BACKEND=gloo: two ranks / two consumers share the card): the line of either
+    workload has n_gpus 2, names its workload, and carries non-null roofline + cpu_baseline — what the driver's
+    1/2/4/8 run will print on an 8-GPU node, exercised before that node exists."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["TW_BENCH_BACKEND"] = "gloo"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--mode", mode, "--steps", "5", "--warmup", "1",
+           "--batch", "64", "--slots", "32", "--cpu-pairs", "4", "--no-extras"]
+    d = _line(subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900))
+    one = _line(subprocess.run([a if a != "2" else "1" for a in cmd], capture_output=True, text=True, env=env, timeout=900))
+    for x, n in ((d, 2), (one, 1)):
+        assert x["n_gpus"] == n and x["config"]["mode"] == mode and x["config"]["workload"].startswith(mode + ":")
+        assert x["value"] > 0 and x["unit"] == "pairs/s" and x["scaling"] == "weak"
+        for key in ("roofline", "roofline_polyexp"):
+            rf = x[key]
+            assert rf is not None and rf["bound"] == "hbm" and 0.05 < rf["frac"] < 1.0 and rf["launches"] > 0, (key, rf)
+            assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+        c = x["cpu_baseline"]
+        assert c is not None and c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1
+    assert d["config"]["rehearsal"] and one["config"]["rehearsal"] is None
+    if mode == "queue":
+        q = d["queue_sharded"]
+        assert q["consumers"] == 2 and q["all_consumers_warm"] is True and q["errors"] == 0
+        assert all(c["pairs"] > 0 for c in q["per_consumer"]), q["per_consumer"]   # no idle consumer in the timed region
+        assert sum(c["pairs"] for c in q["per_consumer"]) == q["pairs"]

@@ -542,7 +542,9 @@ def test_two_stream_lanes_gaussian_and_box(twflow, oracle, kw, monkeypatch):
                                  dict(TW_POLY_VARIANT="2"), dict(TW_LATENCY_STREAMS="0"),
                                  dict(TW_LATENCY_MIN_PX="0", TW_ROCTX="1"), dict(TW_BLUR_NOMASK="1"),
                                  dict(TW_BLUR_VARIANT="5"), dict(TW_BLUR_VARIANT="60"), dict(TW_BLUR_VARIANT="61"),
-                                 dict(TW_PP_WAVES="100000"), dict(TW_CHUNK_TILES="100"), dict(TW_LANES="2", TW_CHUNK_TILES="100")])
+                                 dict(TW_PP_WAVES="100000"), dict(TW_CHUNK_TILES="100"), dict(TW_LANES="2", TW_CHUNK_TILES="100"),
+                                 dict(TW_BLUR_VARIANT="2"), dict(TW_BLUR_VARIANT="6"), dict(TW_BLUR_VARIANT="7"),
+                                 dict(TW_BLUR_VARIANT="8"), dict(TW_UPD_NY="1"), dict(TW_LAT_GRAPH="1"), dict(TW_LAT_S2_LEVELS="0")])
 def test_every_kernel_variant_behind_a_switch_is_bit_exact(twflow, oracle, env, monkeypatch):
     """The A/B switches of DESIGN.md §7 select other kernels / schedules for the same arithmetic (small-grid blur
     tiles, the plane-parallel blur, scalar / 240x16 polyexp, one- or two-stream single-pair schedule, 480-column
@@ -558,13 +560,76 @@ def test_every_kernel_variant_behind_a_switch_is_bit_exact(twflow, oracle, env, 
         b[h // 2: h // 2 + 20, w // 3: w // 3 + 40] = 30
         wx, wy = oracle.farneback(a, b)
         want = oracle.span_scan(wx, wy, 7, 1.0)
-        with twflow.Engine(0, twflow.default_params(), slots=3) as e:
+        # the A/B kernels live in libtwflow_variants.so (make VARIANTS=1), not in the product library
+        with twflow.use_variants_library() as L, twflow.Engine(0, twflow.default_params(), slots=3) as e:
+            assert L.tw_has_variants() == 1
             gx, gy, _ = e.calculate_internal(a, b)           # one pair: latency schedule
             tk = [e.submit(a, b, 7, 1.0) for _ in range(3)]  # a batch of three
             got = [e.wait(t)["vector"] for t in tk]
         assert_same(gx, wx, "flowx %r %dx%d" % (env, w, h))
         assert_same(gy, wy, "flowy %r %dx%d" % (env, w, h))
         assert got == [want, want, want]
+
+
+@pytest.mark.parametrize("env", [dict(TW_BLUR_VARIANT="60"), dict(TW_POLY_VARIANT="0"), dict(TW_BLUR_SMALL="3"),
+                                 dict(TW_UPD_NY="1")])
+def test_product_library_refuses_the_ab_kernel_switches(twflow, env, monkeypatch):
+    """the product library carries only kernels a launch reaches with no environment variable set; a
+    switch that names one of the measured-slower A/B kernels is refused (loudly), not silently served by another."""
+    assert twflow.lib().tw_has_variants() == 0
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    with pytest.raises(twflow.TwError) as ei:
+        twflow.Engine(0, twflow.default_params(), slots=1)
+    assert ei.value.code == twflow.TW_E_UNSUPPORTED
+
+
+def test_single_pair_schedule_as_a_captured_graph(twflow, oracle, monkeypatch):
+    """BASELINE config 2, opt-in TW_LAT_GRAPH=1 (slower on this runtime, kept as an A/B switch): a one-pair batch
+    replays a captured hipGraph of its two-stream schedule.  The graph is really what ran (tw_debug_graphs), a second
+    size gets its own, results stay bit-exact when the same graph is replayed for other images, and an option that
+    changes the schedule captures anew."""
+    import synth
+    monkeypatch.setenv("TW_LAT_GRAPH", "1")
+    with twflow.Engine(0, twflow.default_params(), slots=1) as e:
+        L = twflow.lib()
+        # (largest first: a workspace that has to grow drops the captured schedules, which hold its addresses)
+        for i, (h, w) in enumerate([(540, 960), (480, 640), (480, 640)]):
+            a, b = synth.make_pair(i, h, w)
+            wx, wy = oracle.farneback(a, b)
+            want = oracle.span_scan(wx, wy, 10, 5.0)
+            da, db = e.upload(a), e.upload(b)
+            for rep in range(2):
+                assert e.wait(e.submit_dev(da, db, w, h, w, 10, 5.0))["vector"] == want
+            gx, gy, _ = e.calculate_internal(a, b)  # span 0 + host upload: another key
+            assert_same(gx, wx, "flowx %dx%d" % (w, h))
+            assert_same(gy, wy, "flowy %dx%d" % (w, h))
+        assert L.tw_debug_graphs(e._h) == 4  # (640x480, 960x540) x (span 10 from HBM, span 0 from the host)
+        e.set_option(twflow.OPT_SCAN_FUSED_FINAL, 1)
+        assert e.wait(e.submit_dev(da, db, w, h, w, 10, 5.0))["vector"] == want
+        assert L.tw_debug_graphs(e._h) == 5
+
+
+def test_debug_stamps_buffer_survives_the_latency_workspace(twflow, oracle, monkeypatch):
+    """the first flush of an engine grows the single-pair workspace; a stray hipFree there used to release
+    the TW_DEBUG_STAMPS buffer, which tw_pyr_taps then kept writing to (silent corruption of lat_I / lat_R, double
+    free at destroy).  One 1080p pair through submit/wait with stamps on: bit-exact flow, 256 stamps read back."""
+    import ctypes as C
+    import synth
+    monkeypatch.setenv("TW_DEBUG_STAMPS", "1")
+    a, b = synth.make_pair(1, 1080, 1920)
+    wx, wy = oracle.farneback(a, b)
+    with twflow.Engine(0, twflow.default_params(), slots=1) as e:
+        res = e.diff(a, b, 10, 5.0)                      # submit/wait: reaches reserve_workspace
+        gx, gy, _ = e.calculate_internal(a, b)
+        buf = (C.c_ulonglong * 256)()
+        twflow.lib().tw_debug_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
+        n = twflow.lib().tw_debug_stamps(e._h, buf)
+    assert n == 256
+    assert any(buf[i] for i in range(256)), "no stamp was written"
+    assert_same(gx, wx, "flowx with stamps")
+    assert_same(gy, wy, "flowy with stamps")
+    assert res["vector"] == oracle.span_scan(wx, wy, 10, 5.0)
 
 
 def test_soak_many_sizes_plan_cache_eviction_and_mixed_batches(twflow, oracle):

@@ -86,6 +86,64 @@ int main() {
     assert int(r.stdout.strip()) >= 3, "20 bursts of 16 jobs were served by %s of 8 consumers" % r.stdout.strip()
 
 
+def _fake_sysfs(root, devices):
+    """A pretend /sys: devices = [(bus id, numa node)], nodes 0 and 1 own the first / second half of this process's
+    CPUs."""
+    cpus = sorted(os.sched_getaffinity(0))
+    half = max(1, len(cpus) // 2)
+    nodes = {0: cpus[:half], 1: cpus[half:] or cpus[:half]}
+    for bus, node in devices:
+        d = os.path.join(root, "bus", "pci", "devices", bus)
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "numa_node"), "w") as f:
+            f.write("%d\n" % node)
+    for n, cs in nodes.items():
+        d = os.path.join(root, "devices", "system", "node", "node%d" % n)
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "cpulist"), "w") as f:
+            # a list with a range, a single CPU and one CPU this process may not use (must be ignored)
+            f.write(",".join(str(c) for c in cs) + ",4000\n")
+    return nodes
+
+
+def test_consumers_are_placed_on_their_gpus_numa_node(tmp_path):
+    """VERDICT r2 #1 / SURVEY 8(e): consumer i (device i % devices, src/consumer.cpp:18-24) runs on the CPUs of its
+    GPU's NUMA node, bound before its engine and page-locked buffers exist.  Stub backend, four pretend devices on
+    two pretend nodes, six consumers; TW_NUMA=0 leaves every thread where it was; a device without NUMA information
+    (numa_node -1) is left alone."""
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    if len(os.sched_getaffinity(0)) < 2:
+        pytest.skip("needs two CPUs")
+    r = subprocess.run(["make", "-s", "-C", HOST, "numa"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    devs = [("0000:05:00.0", 0), ("0000:26:00.0", 0), ("0000:85:00.0", 1), ("0000:a6:00.0", -1)]
+    nodes = _fake_sysfs(str(tmp_path), devs)
+    allowed = sorted(os.sched_getaffinity(0))
+    env = dict(os.environ, TW_SYSFS_ROOT=str(tmp_path), TW_STUB_DEVICES="4", TW_STUB_PCI=",".join(b for b, _ in devs),
+               TW_CONSUMERS_PER_DEVICE="2")
+    env.pop("TW_NUMA", None)
+    r = subprocess.run([os.path.join(HOST, "build", "numa_driver"), "6", "96"], capture_output=True, text=True,
+                       timeout=120, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert len(out["consumers"]) == 6 and out["pairs"] == 96
+    assert out["main_thread_cpus"] == len(allowed)  # the caller's thread is never re-bound
+    for c in out["consumers"]:
+        bus, node = devs[c["id"] % 4]
+        assert c["device"] == c["id"] % 4 and c["pci"] == bus
+        if node >= 0:
+            assert c["numa_node"] == node and c["cpus"] == nodes[node], c
+        else:
+            assert c["numa_node"] == -1 and c["cpus"] == allowed, c
+    # the switch: nobody is bound
+    r = subprocess.run([os.path.join(HOST, "build", "numa_driver"), "4", "32"], capture_output=True, text=True,
+                       timeout=120, env=dict(env, TW_NUMA="0"))
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert all(c["numa_node"] == -1 and c["cpus"] == allowed for c in out["consumers"])
+
+
 @pytest.mark.gpu
 def test_c99_consumer_device_branch(tmp_path):
     """tests/test_abi.py::test_header_is_plain_c_and_links on a GPU box: the C99 consumer's tw_diff_u8 call runs

@@ -16,9 +16,11 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
 #include <map>
+#include <mutex>
 #include <string>
-#include <unordered_map>
+#include <tuple>
 #include <utility>
 #include <vector>
 
@@ -235,6 +237,7 @@ struct Plan {
     int levels = 0;  // index of the coarsest level
     std::vector<LevelPlan> lv;
     std::vector<void*> owned;  // device allocations
+    unsigned long long last_use = 0;  // engine's plan clock at the last get_plan (LRU eviction)
 };
 
 constexpr int HOST_RECS = 1024;  // flagged vectors per pair copied back eagerly
@@ -276,6 +279,18 @@ struct Ctx {
 
 struct ProfPair {
     hipEvent_t a, b;
+};
+
+// what a captured single-pair schedule depends on besides the engine's (fixed) parameters and workspace addresses
+struct GraphKey {
+    int w, h, span;
+    long long stride;
+    int aligned4, scan_fused, poly_f32;
+    bool operator<(const GraphKey& o) const
+    {
+        return std::tie(w, h, span, stride, aligned4, scan_fused, poly_f32) <
+               std::tie(o.w, o.h, o.span, o.stride, o.aligned4, o.scan_fused, o.poly_f32);
+    }
 };
 
 // Optional roctx ranges (TW_ROCTX=1): one range per batch and per pyramid level on the submitting thread, so that a
@@ -331,6 +346,7 @@ struct tw_engine {
     int cur = 0;  // context accepting submissions
     int64_t next_ticket = 1;
     std::map<std::pair<int, int>, Plan*> plans;
+    unsigned long long plan_clock = 0;
     PolyCoef pc;
     WinCoef wc;
     int win_m = 15;
@@ -345,6 +361,7 @@ struct tw_engine {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int upd_ny = 2;        // TW_UPD_NY: pixels per lane of tw_update_matrices (1 or 2)
     int scan_fused = 0;    // TW_OPT_SCAN_FUSED_FINAL
+    int poly_f32 = 0;      // TW_OPT_POLYEXP_F32 (measurement variant: float accumulators, not bit-exact)
     int pyr_generic = 0;   // TW_PYR_GENERIC=1: always the generic pyramid kernel, 2: tw_pyr_level_lds for every level (A/B)
     int blur_variant = 4;  // 4: tw_blur_solve4 (default); 8: tw_blur_solve8 (packed f32) — TW_BLUR_VARIANT
     int pp_waves = 512;    // TW_PP_WAVES: below this many waves of 96x8 tiles a level takes the plane-parallel kernel
@@ -366,10 +383,11 @@ struct tw_engine {
     float *lat_I = nullptr, *lat_R = nullptr;
     size_t lat_cap = 0;  // floats in lat_I (lat_R holds 5x)
     std::vector<hipEvent_t> lat_ev;
+    int lat_s2_max = 1000;  // TW_LAT_S2_LEVELS: finest..this level's image-only work goes to the second stream
+    int lat_graph = 0;  // TW_LAT_GRAPH=1: replay the single-pair schedule from a captured hipGraph (measured SLOWER on
+                        // ROCm 7.2: 0.55 ms vs 0.37 ms — profiles/r03_latency.md — so it is opt-in, kept for re-measuring)
+    std::map<GraphKey, hipGraphExec_t> lat_graphs;  // captured single-pair schedules (dropped whenever a buffer moves)
     hipStream_t copy_stream = nullptr;  // host -> device image uploads, overlapped with the compute stream
-    // answers of hipPointerGetAttributes per image pointer (is it page-locked?): the query costs microseconds and, on
-    // this runtime, about 1 KB of host memory that never comes back (a 300 000-pair soak grew by 2 KB per pair)
-    std::unordered_map<uintptr_t, bool> pin_cache;
     const uint8_t** d_ptrs = nullptr;  // [2*cap]
     int* d_count = nullptr;            // [cap]
     float2* d_grid = nullptr;          // [cap][G] dense grid samples (dx,dy)
@@ -460,6 +478,13 @@ int pyr_nrows_max(const ResizeTab& t, int h, int h0, int r)
     return mx;
 }
 
+// captured schedules hold workspace and table addresses: whenever one of those may move, they go
+void drop_graphs(tw_engine* e)
+{
+    for (auto& kv : e->lat_graphs) (void)hipGraphExecDestroy(kv.second);
+    e->lat_graphs.clear();
+}
+
 void free_plan(Plan* pl)
 {
     for (void* d : pl->owned) (void)hipFree(d);
@@ -471,20 +496,28 @@ tw_status get_plan(tw_engine* e, int w0, int h0, Plan** out)
     auto key = std::make_pair(w0, h0);
     auto it = e->plans.find(key);
     if (it != e->plans.end()) {
+        it->second->last_use = ++e->plan_clock;
         *out = it->second;
         return TW_OK;
     }
     if (e->plans.size() >= 64) {
         // a long-running service that sees arbitrary image sizes must not collect plans (and their device tables) for
-        // ever: every 64 new sizes the cache is emptied.  Queued launches still read the tables, so drain first.
+        // ever: the 65th size evicts the least recently used one (emptying the whole cache made a service
+        // that cycles through 65 sizes rebuild all of them on every wrap).  Queued launches may still read the evicted
+        // plan's tables, so the streams are drained first — once per new size, and only beyond 64 sizes.
+        auto victim = e->plans.begin();
+        for (auto jt = e->plans.begin(); jt != e->plans.end(); ++jt)
+            if (jt->second->last_use < victim->second->last_use) victim = jt;
         TW_HIP(e, hipStreamSynchronize(e->stream));
         TW_HIP(e, hipStreamSynchronize(e->stream2));
-        for (auto& kv : e->plans) free_plan(kv.second);
-        e->plans.clear();
+        drop_graphs(e);
+        free_plan(victim->second);
+        e->plans.erase(victim);
     }
     Plan* pl = new Plan();
     pl->w0 = w0;
     pl->h0 = h0;
+    pl->last_use = ++e->plan_clock;
     const int req = std::min(std::max(e->p.pyrLevels, 0), 60);
     pl->levels = plan_levels(w0, h0, e->p.pyrScale, req);
     pl->lv.resize(pl->levels + 1);
@@ -593,6 +626,7 @@ tw_status reserve_workspace(tw_engine* e, const Plan* pl, int span, bool need_im
     if (!grow) return TW_OK;
     TW_HIP(e, hipStreamSynchronize(e->stream));
     TW_HIP(e, hipStreamSynchronize(e->stream2));
+    drop_graphs(e);
     if (need > e->ws_elems) {
         if (e->I) (void)hipFree(e->I);
         if (e->R) (void)hipFree(e->R);
@@ -607,8 +641,7 @@ tw_status reserve_workspace(tw_engine* e, const Plan* pl, int span, bool need_im
         e->ws_elems = need;
     }
     if (e->lat_streams && need_lat > e->lat_cap) {
-        if (e->dbg_stamps) (void)hipFree(e->dbg_stamps);
-    if (e->lat_I) (void)hipFree(e->lat_I);
+        if (e->lat_I) (void)hipFree(e->lat_I);
         if (e->lat_R) (void)hipFree(e->lat_R);
         e->lat_I = e->lat_R = nullptr;
         e->lat_cap = 0;
@@ -693,11 +726,13 @@ struct ProfScope {
 template <bool UP>
 void launch_upd_kernel(tw_engine* e, hipStream_t st, int w, int h, int npairs, const UpdArgs& a)
 {
+#ifdef TW_VARIANTS
     if (e->upd_ny == 1) {
         hipLaunchKernelGGL((tw_update_matrices<UP, 1>), dim3((w + 63) / 64, (h + 3) / 4, npairs), dim3(256), 0, st, a);
-    } else {
-        hipLaunchKernelGGL((tw_update_matrices<UP, 2>), dim3((w + 63) / 64, (h + 7) / 8, npairs), dim3(256), 0, st, a);
+        return;
     }
+#endif
+    hipLaunchKernelGGL((tw_update_matrices<UP, 2>), dim3((w + 63) / 64, (h + 7) / 8, npairs), dim3(256), 0, st, a);
 }
 
 // ---- kernel launch helpers (nz = images or pairs in this launch) -------------------------------------
@@ -789,6 +824,7 @@ tw_status launch_polyexp(tw_engine* e, hipStream_t st, int w, int h, int ld, lon
     a.c = e->pc;
     dim3 grid((w + PE_TW - 1) / PE_TW, (h + PE_TH - 1) / PE_TH, nimg);
     ProfScope pscope(e, st, TW_K_POLYEXP, level);
+#ifdef TW_VARIANTS
     if (e->poly_variant == 0) {
         // scalar-f32 kernel (A/B: TW_POLY_VARIANT=0)
         switch (e->p.polyN) {
@@ -803,8 +839,19 @@ tw_status launch_polyexp(tw_engine* e, hipStream_t st, int w, int h, int ld, lon
         }
         return TW_OK;
     }
+#endif
+    if (e->poly_f32) {
+        // measurement variant (TW_OPT_POLYEXP_F32): float horizontal accumulators — NOT bit-exact, never the default
+        switch (e->p.polyN) {
+            case 5: hipLaunchKernelGGL((tw_polyexp_pk<5, 8, true>), grid, dim3(256), 0, st, a); break;
+            case 7: hipLaunchKernelGGL((tw_polyexp_pk<7, 8, true>), grid, dim3(256), 0, st, a); break;
+            default: e->err = "TW_OPT_POLYEXP_F32 needs polyN 5 or 7"; return TW_E_UNSUPPORTED;
+        }
+        return TW_OK;
+    }
     // packed-f32 kernel, 240 x 8 tiles; TW_POLY_VARIANT=2 selects 240 x 16 tiles (960 two-by-two items = 15 full
     // waves of the horizontal pass, 30-row window per 16 output rows, 48 KB LDS: measured equal within the noise)
+#ifdef TW_VARIANTS
     const bool t16 = e->poly_variant == 2;
     if (t16) grid.y = (h + 15) / 16;
 #define TW_PK_CASE(n)                                                                        \
@@ -812,6 +859,10 @@ tw_status launch_polyexp(tw_engine* e, hipStream_t st, int w, int h, int ld, lon
         if (t16) hipLaunchKernelGGL((tw_polyexp_pk<n, 16>), grid, dim3(256), 0, st, a);      \
         else hipLaunchKernelGGL((tw_polyexp_pk<n, 8>), grid, dim3(256), 0, st, a);           \
         break;
+#else
+#define TW_PK_CASE(n)                                                                        \
+    case n: hipLaunchKernelGGL((tw_polyexp_pk<n, 8>), grid, dim3(256), 0, st, a); break;
+#endif
     switch (e->p.polyN) {
         TW_PK_CASE(1) TW_PK_CASE(2) TW_PK_CASE(3) TW_PK_CASE(4) TW_PK_CASE(5) TW_PK_CASE(6) TW_PK_CASE(7)
         default: e->err = "polyN must be 1..7"; return TW_E_UNSUPPORTED;
@@ -884,11 +935,15 @@ void launch_blur(tw_engine* e, hipStream_t st, int w, int h, int ld, long long p
         return;
     }
     ProfScope pscope(e, st, TW_K_BLUR_SOLVE, level);
+#ifdef TW_VARIANTS
     if (e->win_m == 15 && e->blur_variant == 8) {
         // packed-f32 structure (same speed as v4 at 1080p, lower VALU load); TW_BLUR_VARIANT=8 for A/B
         if (wide) hipLaunchKernelGGL((tw_blur_solve8<15, 256, 16, 8, true, true>), dim3((w + 223) / 224, gy, npairs), dim3(256), 0, st, a);
         else hipLaunchKernelGGL((tw_blur_solve8<15, 128, 16, 8, true, true>), dim3((w + 95) / 96, gy, npairs), dim3(128), 0, st, a);
-    } else if (e->win_m == 15) {
+        return;
+    }
+#endif
+    if (e->win_m == 15) {
         // Small grids (a single pair, the coarse levels): a level that would launch fewer than two workgroups per
         // CU takes smaller tiles, so that more CUs share it and each workgroup's serial V -> H -> S chain is shorter
         // (BASELINE config 2, single-pair latency).  Batched launches always have enough tiles and keep the big ones.
@@ -905,12 +960,15 @@ void launch_blur(tw_engine* e, hipStream_t st, int w, int h, int ld, long long p
             a.rot = a.xsh;
             const dim3 grid((w + a.xsh + tw - 1) / tw, (h + th - 1) / th, npairs);
             if (small == 1) hipLaunchKernelGGL((tw_blur_solve4<15, 128, 16, 8, true>), grid, dim3(128), 0, st, a);
+#ifdef TW_VARIANTS
             else if (small == 2) hipLaunchKernelGGL((tw_blur_solve4<15, 128, 16, 4, true>), grid, dim3(128), 0, st, a);
             else if (small == 3) hipLaunchKernelGGL((tw_blur_solve4<15, 64, 16, 4, true>), grid, dim3(64), 0, st, a);
-            else if (small == 4) hipLaunchKernelGGL((tw_blur_solve_pp<15, 64, 16, 8>), grid, dim3(320), 0, st, a);
-            else hipLaunchKernelGGL((tw_blur_solve_pp<15, 128, 16, 8>), grid, dim3(640), 0, st, a);
+            else if (small == 5) hipLaunchKernelGGL((tw_blur_solve_pp<15, 128, 16, 8>), grid, dim3(640), 0, st, a);
+#endif
+            else hipLaunchKernelGGL((tw_blur_solve_pp<15, 64, 16, 8>), grid, dim3(320), 0, st, a);
             return;
         }
+#ifdef TW_VARIANTS
         if (wide && (e->blur_variant == 60 || e->blur_variant == 61)) {
             // plane pipeline through a two-plane LDS ring (tw_blur_solve6), A/B
             a.xsh = ((w + 16 + 223) / 224 == (w + 223) / 224) ? 16 : 0;
@@ -929,19 +987,24 @@ void launch_blur(tw_engine* e, hipStream_t st, int w, int h, int ld, long long p
             hipLaunchKernelGGL((tw_blur_solve4<15, 512, 16, 8, true>), dim3((w + a.xsh + 479) / 480, gy, npairs), dim3(512), 0, st, a);
             return;
         }
+#endif
         // shift the tile grid 16 px left when that costs no extra tile column (see the kernel)
         const int tw = wide ? 224 : 96;
         a.xsh = ((w + 16 + tw - 1) / tw == (w + tw - 1) / tw) ? 16 : 0;
         a.rot = a.xsh;
-        if (wide && e->blur_variant == 2) hipLaunchKernelGGL((tw_blur_solve4y<15, 256, 16, 8, 2>), dim3((w + a.xsh + 223) / 224, (h + 15) / 16, npairs), dim3(256), 0, st, a);
-        else if (wide && e->blur_variant == 7) hipLaunchKernelGGL((tw_blur_solve4<15, 256, 16, 8, true, 2, 2, 2, true, false>), dim3((w + a.xsh + 223) / 224, gy, npairs), dim3(256), 0, st, a);
-        else if (wide && e->blur_variant == 6) hipLaunchKernelGGL((tw_blur_solve4<15, 256, 16, 8, true, 2, 2, 2, false>), dim3((w + a.xsh + 223) / 224, gy, npairs), dim3(256), 0, st, a);
-        else if (wide) hipLaunchKernelGGL((tw_blur_solve4<15, 256, 16, 8, true>), dim3((w + a.xsh + 223) / 224, gy, npairs), dim3(256), 0, st, a);
+#ifdef TW_VARIANTS
+        if (wide && e->blur_variant == 2) { hipLaunchKernelGGL((tw_blur_solve4y<15, 256, 16, 8, 2>), dim3((w + a.xsh + 223) / 224, (h + 15) / 16, npairs), dim3(256), 0, st, a); return; }
+        if (wide && e->blur_variant == 7) { hipLaunchKernelGGL((tw_blur_solve4<15, 256, 16, 8, true, 2, 2, 2, true, false>), dim3((w + a.xsh + 223) / 224, gy, npairs), dim3(256), 0, st, a); return; }
+        if (wide && e->blur_variant == 6) { hipLaunchKernelGGL((tw_blur_solve4<15, 256, 16, 8, true, 2, 2, 2, false>), dim3((w + a.xsh + 223) / 224, gy, npairs), dim3(256), 0, st, a); return; }
+#endif
+        if (wide) hipLaunchKernelGGL((tw_blur_solve4<15, 256, 16, 8, true>), dim3((w + a.xsh + 223) / 224, gy, npairs), dim3(256), 0, st, a);
         else hipLaunchKernelGGL((tw_blur_solve4<15, 128, 16, 8, true>), dim3((w + a.xsh + 95) / 96, gy, npairs), dim3(128), 0, st, a);
     } else if (e->win_m == 25) {
         // winSize 50/51 (BASELINE config 5): packed-f32 structure, single 58-row register window
-        if (wide && e->blur_variant != 8) hipLaunchKernelGGL((tw_blur_solve4<25, 256, 32, 8, true, 2, 2, 2, false, false>), dim3((w + 191) / 192, gy, npairs), dim3(256), 0, st, a);
-        else if (wide) hipLaunchKernelGGL((tw_blur_solve8<25, 256, 32, 8, true, false>), dim3((w + 191) / 192, gy, npairs), dim3(256), 0, st, a);
+#ifdef TW_VARIANTS
+        if (wide && e->blur_variant == 8) { hipLaunchKernelGGL((tw_blur_solve8<25, 256, 32, 8, true, false>), dim3((w + 191) / 192, gy, npairs), dim3(256), 0, st, a); return; }
+#endif
+        if (wide) hipLaunchKernelGGL((tw_blur_solve4<25, 256, 32, 8, true, 2, 2, 2, false, false>), dim3((w + 191) / 192, gy, npairs), dim3(256), 0, st, a);
         else hipLaunchKernelGGL((tw_blur_solve8<25, 128, 32, 8, true, false>), dim3((w + 63) / 64, gy, npairs), dim3(128), 0, st, a);
     } else {
         // any other window size: generic kernel (same arithmetic, runtime loops)
@@ -1051,18 +1114,31 @@ tw_status flush_ctx(tw_engine* e, Ctx& c)
             lat_off[k] = off;
             off += (size_t)pl->lv[k].ps * 2;
         }
+    }
+    // Everything between the batch's start event and the ordered scan, as one function: the single-pair schedule
+    // replays it from a captured hipGraph (below), every other batch enqueues it directly.
+    auto enqueue_levels = [&]() -> tw_status {
+    if (lat) {
         TW_HIP(e, hipEventRecord(e->ev_fork, st));  // pointer table + uploads + the previous batch's use of lat_I / lat_R
         TW_HIP(e, hipStreamWaitEvent(e->stream2, e->ev_fork, 0));
-        // the coarsest level's images are needed at once: they stay on the main stream (no hand-off to wait for);
-        // the finer levels' are ready long before the flow chain reaches them
-        for (int k = pl->levels; k >= 0; k--) {
-            const LevelPlan& L = pl->lv[k];
-            hipStream_t ws = k == pl->levels ? st : e->stream2;
-            launch_pyr(e, ws, pl, k, e->d_ptrs, stride, e->lat_I + lat_off[k], 2);
-            if ((r = launch_polyexp(e, ws, L.w, L.h, L.ld, L.ps, e->lat_I + lat_off[k], e->lat_R + 5 * lat_off[k], 2, k)))
-                return r;
-            if (k < pl->levels) TW_HIP(e, hipEventRecord(e->lat_ev[k], e->stream2));
-        }
+    }
+    // image-only work of level k in the single-pair schedule: the coarsest level's is needed at once and stays on the
+    // main stream (no hand-off to wait for); the finer levels' go to the second stream.  It is ENQUEUED one level
+    // ahead of the flow chain that consumes it (round 3: with all of it enqueued up front the host needed ~40 us for
+    // those launches before the first flow-chain kernel was even submitted — the GPU sat idle behind the host).
+    auto lat_images = [&](int k) -> tw_status {
+        const LevelPlan& L = pl->lv[k];
+        const bool second = k < pl->levels && k <= e->lat_s2_max;
+        hipStream_t ws = second ? e->stream2 : st;
+        launch_pyr(e, ws, pl, k, e->d_ptrs, stride, e->lat_I + lat_off[k], 2);
+        tw_status rr = launch_polyexp(e, ws, L.w, L.h, L.ld, L.ps, e->lat_I + lat_off[k], e->lat_R + 5 * lat_off[k], 2, k);
+        if (rr) return rr;
+        if (second) TW_HIP(e, hipEventRecord(e->lat_ev[k], e->stream2));
+        return TW_OK;
+    };
+    if (lat) {
+        if ((r = lat_images(pl->levels))) return r;
+        if (pl->levels >= 1 && (r = lat_images(pl->levels - 1))) return r;
     }
     for (int lane = 0; lane < nlanes; lane++) {
         hipStream_t ls = lane == 0 ? st : e->stream2;
@@ -1085,7 +1161,7 @@ tw_status flush_ctx(tw_engine* e, Ctx& c)
                     k < pl->levels ? e->flow[k + 1] + (size_t)j0 * 2 * pl->lv[k + 1].ps : nullptr;
                 if (lat) {
                     R = e->lat_R + 5 * lat_off[k];
-                    if (k < pl->levels) TW_HIP(e, hipStreamWaitEvent(ls, e->lat_ev[k], 0));
+                    if (k < pl->levels && k <= e->lat_s2_max) TW_HIP(e, hipStreamWaitEvent(ls, e->lat_ev[k], 0));
                 } else {
                     launch_pyr(e, ls, pl, k, e->d_ptrs + 2 * j0, stride, I, 2 * nc);
                     if ((r = launch_polyexp(e, ls, L.w, L.h, L.ld, L.ps, I, R, 2 * nc, k))) return r;
@@ -1128,12 +1204,66 @@ tw_status flush_ctx(tw_engine* e, Ctx& c)
                     ProfScope pscope(e, ls, TW_K_SCAN, 0);
                     hipLaunchKernelGGL(tw_span_gather, dim3((g.gw + 63) / 64, (g.gh + 3) / 4, nc), dim3(256), 0, ls, g);
                 }
+                // the image-only work two levels below goes out once this level's chain is enqueued
+                if (lat && k >= 2 && (r = lat_images(k - 2))) return r;
             }
         }
     }
     if (nlanes > 1) {
         TW_HIP(e, hipEventRecord(e->ev_join, e->stream2));
         TW_HIP(e, hipStreamWaitEvent(st, e->ev_join, 0));
+    }
+    return TW_OK;
+    };  // enqueue_levels
+
+    // Single pair (BASELINE config 2): ~26 launches and ~10 event operations, half of them kernels of 5-10 us.  With
+    // TW_LAT_GRAPH=1 the whole DAG — both streams, their hand-offs — is captured once per (size, span, stride,
+    // alignment, options) and replayed with one hipGraphLaunch; the ordered scan and the result copies stay outside
+    // (their targets belong to the batch context).  Round 3 measured it: the host is NOT what holds the schedule back
+    // (the direct enqueue takes 110 us of host time for 375 us of GPU time, TW_DEBUG_HOSTTIME), and the replayed graph
+    // is slower (0.55 ms: kernels of the forked branch stretch to ~40 us quanta behind cross-queue signals), so the
+    // direct path is the default and the graph an opt-in A/B switch (profiles/r03_latency.md).
+    bool prof_on = false;
+    for (int i = 0; i < TW_K_COUNT; i++) prof_on = prof_on || e->prof_level[i] != -2;
+    bool launched_graph = false;
+    if (lat && e->lat_graph && !prof_on) {
+        const GraphKey key{c.w, c.h, c.span, stride, e->img_aligned4, e->scan_fused, e->poly_f32};
+        auto git = e->lat_graphs.find(key);
+        if (git == e->lat_graphs.end()) {
+            hipGraph_t graph = nullptr;
+            hipGraphExec_t exec = nullptr;
+            bool ok = hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed) == hipSuccess;
+            tw_status br = TW_OK;
+            if (ok) {
+                br = enqueue_levels();
+                ok = hipStreamEndCapture(st, &graph) == hipSuccess && graph != nullptr && br == TW_OK;
+            }
+            if (br != TW_OK) {
+                if (graph) (void)hipGraphDestroy(graph);
+                (void)hipGetLastError();
+                return br;
+            }
+            ok = ok && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess;
+            if (graph) (void)hipGraphDestroy(graph);
+            if (ok) {
+                git = e->lat_graphs.emplace(key, exec).first;
+            } else {
+                (void)hipGetLastError();
+                e->lat_graph = 0;  // this runtime cannot capture the schedule: direct launches from now on
+            }
+        }
+        if (git != e->lat_graphs.end()) {
+            TW_HIP(e, hipGraphLaunch(git->second, st));
+            launched_graph = true;
+        }
+    }
+    if (!launched_graph) {
+        static const bool host_time = getenv("TW_DEBUG_HOSTTIME") != nullptr;  // diagnostic: host cost of the enqueue
+        const auto t_h0 = std::chrono::steady_clock::now();
+        if ((r = enqueue_levels())) return r;
+        if (host_time)
+            fprintf(stderr, "twflow: enqueue of %d pair(s) %dx%d took %.1f us on the host\n", n, c.w, c.h,
+                    std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_h0).count());
     }
     if (c.span > 0) {
         const LevelPlan& L = pl->lv[0];
@@ -1180,26 +1310,38 @@ tw_status check_dims(tw_engine* e, int width, int height)
     return TW_OK;
 }
 
-// true for page-locked host memory (hipHostMalloc / hipHostRegister); plain malloc memory makes the query fail
-bool host_pinned_query(const void* p)
-{
-    hipPointerAttribute_t at;
-    if (hipPointerGetAttributes(&at, p) != hipSuccess) {
-        (void)hipGetLastError();
-        return false;
+// Page-locked host ranges this library handed out (tw_host_alloc) or was told about (tw_host_register): process-wide,
+// because such memory is portable across devices and one engine may free what another one uploads from (a
+// per-engine cache of hipPointerGetAttributes answers went stale exactly then, and a stale "pinned" answer turns the
+// safe staged upload into a DMA from pageable memory).  Any pointer outside these ranges is treated as pageable and
+// staged — always correct, at the cost of one memcpy.  No runtime query per submit (each one also cost ~1 KB of host
+// memory that never came back: DESIGN.md §7 "Soak").
+struct PinRegistry {
+    std::mutex m;
+    std::map<uintptr_t, size_t> ranges;  // start -> bytes
+    void add(const void* p, size_t n)
+    {
+        std::lock_guard<std::mutex> lk(m);
+        ranges[(uintptr_t)p] = n;
     }
-    return at.type == hipMemoryTypeHost;
-}
-
-bool host_pinned(tw_engine* e, const void* p)
+    bool remove(const void* p)
+    {
+        std::lock_guard<std::mutex> lk(m);
+        return ranges.erase((uintptr_t)p) > 0;
+    }
+    bool covers(const void* p, size_t n)
+    {
+        std::lock_guard<std::mutex> lk(m);
+        auto it = ranges.upper_bound((uintptr_t)p);
+        if (it == ranges.begin()) return false;
+        --it;
+        return (uintptr_t)p >= it->first && (uintptr_t)p + n <= it->first + it->second;
+    }
+};
+PinRegistry& pin_registry()
 {
-    const uintptr_t key = (uintptr_t)p;
-    auto it = e->pin_cache.find(key);
-    if (it != e->pin_cache.end()) return it->second;
-    if (e->pin_cache.size() >= 4096) e->pin_cache.clear();  // a caller that keeps allocating: start over
-    const bool pinned = host_pinned_query(p);
-    e->pin_cache[key] = pinned;
-    return pinned;
+    static PinRegistry r;
+    return r;
 }
 
 tw_status submit_common(tw_engine* e, const uint8_t* h_a, const uint8_t* h_b, const void* d_a, const void* d_b,
@@ -1262,8 +1404,9 @@ tw_status submit_common(tw_engine* e, const uint8_t* h_a, const uint8_t* h_b, co
         }
         uint8_t* dst_a = c->d_img + npx * (2 * j);
         uint8_t* dst_b = c->d_img + npx * (2 * j + 1);
-        if (host_pinned(e, h_a) && host_pinned(e, h_b)) {
-            // page-locked caller memory (tw_host_alloc or hipHostRegister): DMA straight from it.  The caller keeps
+        const size_t span_bytes = (size_t)stride * (size_t)(height - 1) + (size_t)width;
+        if (pin_registry().covers(h_a, span_bytes) && pin_registry().covers(h_b, span_bytes)) {
+            // page-locked caller memory (tw_host_alloc / tw_host_register): DMA straight from it.  The caller keeps
             // the buffers unchanged until tw_wait() of this ticket returns.
             if (stride == width) {
                 // dense rows: plain 1-D transfers (the DMA engines; a pitched 2-D copy may run as a blit kernel on
@@ -1344,11 +1487,36 @@ void tw_default_params(tw_params* p)
     p->flags = 256;
 }
 
+int tw_has_variants(void)
+{
+#ifdef TW_VARIANTS
+    return 1;
+#else
+    return 0;
+#endif
+}
+
 int tw_device_count(void)
 {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
+}
+
+tw_status tw_device_pci_bus_id(int device, char* buf, int cap)
+{
+    if (!buf || cap < 16) return TW_E_BAD_PARAMETER;
+    buf[0] = 0;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return TW_E_DEVICE;
+    if (hipDeviceGetPCIBusId(buf, cap, device) != hipSuccess) {
+        (void)hipGetLastError();
+        buf[0] = 0;
+        return TW_E_DEVICE;
+    }
+    for (char* c = buf; *c; c++)
+        if (*c >= 'A' && *c <= 'F') *c = (char)(*c - 'A' + 'a');  // sysfs names are lower case
+    return TW_OK;
 }
 
 const char* tw_strerror(tw_status s)
@@ -1404,12 +1572,28 @@ tw_status tw_engine_create(int device, const tw_params* params, int slots, tw_en
     if (const char* ev = getenv("TW_BLUR_SMALL")) e->blur_small = atoi(ev);
     if (const char* ev = getenv("TW_PP_WAVES")) e->pp_waves = atoi(ev);
     if (const char* ev = getenv("TW_BLUR_NOMASK")) e->blur_nomask = atoi(ev);
+#ifndef TW_VARIANTS
+    // The measured-slower A/B kernels are compiled only into `make VARIANTS=1` builds (libtwflow_variants.so): a
+    // default build refuses their switches instead of silently running something else.
+    {
+        const bool bad = (e->blur_variant != 4) || (e->poly_variant != 1) || (e->blur_small == 2 || e->blur_small == 3 ||
+                         e->blur_small == 5) || (getenv("TW_UPD_NY") && atoi(getenv("TW_UPD_NY")) == 1);
+        if (bad) {
+            fprintf(stderr, "twflow: TW_BLUR_VARIANT / TW_POLY_VARIANT / TW_BLUR_SMALL=2,3,5 / TW_UPD_NY=1 select kernels "
+                            "that are only in a VARIANTS=1 build (tidal-wave_amd/libtwflow_variants.so)\n");
+            delete e;
+            return TW_E_UNSUPPORTED;
+        }
+    }
+#endif
     if (const char* ev = getenv("TW_DEBUG_STAMPS"))
         if (atoi(ev)) (void)hipMalloc((void**)&e->dbg_stamps, 64 * 4 * sizeof(unsigned long long));
     if (const char* ev = getenv("TW_UPD_NY")) e->upd_ny = atoi(ev) == 1 ? 1 : 2;
     if (const char* ev = getenv("TW_LANES")) e->lanes = std::min(2, std::max(1, atoi(ev)));
     if (const char* ev = getenv("TW_LATENCY_STREAMS")) e->lat_streams = atoi(ev) ? 1 : 0;
     if (const char* ev = getenv("TW_LATENCY_MIN_PX")) e->lat_min_px = atoll(ev);
+    if (const char* ev = getenv("TW_LAT_GRAPH")) e->lat_graph = atoi(ev) ? 1 : 0;
+    if (const char* ev = getenv("TW_LAT_S2_LEVELS")) e->lat_s2_max = atoi(ev);
     // the main stream carries the dependent flow chain: highest priority, so that its small launches are not queued
     // behind the second stream's image-only work
     int prio_lo = 0, prio_hi = 0;
@@ -1443,6 +1627,7 @@ void tw_engine_destroy(tw_engine* e)
     if (!e) return;
     (void)hipSetDevice(e->device);
     (void)hipDeviceSynchronize();
+    drop_graphs(e);
     if (e->I) (void)hipFree(e->I);
     if (e->R) (void)hipFree(e->R);
     if (e->M[0]) (void)hipFree(e->M[0]);
@@ -1636,6 +1821,7 @@ tw_status tw_set_option(tw_engine* e, int option, int value)
     if (!e) return TW_E_BAD_PARAMETER;
     switch (option) {
         case TW_OPT_SCAN_FUSED_FINAL: e->scan_fused = value ? 1 : 0; return TW_OK;
+        case TW_OPT_POLYEXP_F32: e->poly_f32 = value ? 1 : 0; return TW_OK;
         default: e->err = "unknown option"; return TW_E_BAD_PARAMETER;
     }
 }
@@ -1645,6 +1831,7 @@ tw_status tw_host_alloc(tw_engine* e, size_t bytes, void** hptr)
     if (!e || !hptr) return TW_E_BAD_PARAMETER;
     TW_HIP(e, hipSetDevice(e->device));
     TW_HIP(e, hipHostMalloc(hptr, bytes, hipHostMallocPortable));  // usable by the engines of every device (one queue, N consumers)
+    pin_registry().add(*hptr, bytes);
     return TW_OK;
 }
 tw_status tw_host_free(tw_engine* e, void* hptr)
@@ -1652,8 +1839,31 @@ tw_status tw_host_free(tw_engine* e, void* hptr)
     if (!e) return TW_E_BAD_PARAMETER;
     TW_HIP(e, hipSetDevice(e->device));
     TW_HIP(e, hipStreamSynchronize(e->copy_stream));  // an upload may still be reading it
+    if (!pin_registry().remove(hptr)) {
+        e->err = "tw_host_free: not a tw_host_alloc block";
+        return TW_E_BAD_PARAMETER;
+    }
     TW_HIP(e, hipHostFree(hptr));
-    e->pin_cache.clear();  // addresses inside the freed block may come back as ordinary memory
+    return TW_OK;
+}
+tw_status tw_host_register(tw_engine* e, void* hptr, size_t bytes)
+{
+    if (!e || !hptr || !bytes) return TW_E_BAD_PARAMETER;
+    TW_HIP(e, hipSetDevice(e->device));
+    TW_HIP(e, hipHostRegister(hptr, bytes, hipHostRegisterPortable));
+    pin_registry().add(hptr, bytes);
+    return TW_OK;
+}
+tw_status tw_host_unregister(tw_engine* e, void* hptr)
+{
+    if (!e || !hptr) return TW_E_BAD_PARAMETER;
+    TW_HIP(e, hipSetDevice(e->device));
+    TW_HIP(e, hipStreamSynchronize(e->copy_stream));
+    if (!pin_registry().remove(hptr)) {
+        e->err = "tw_host_unregister: not a registered block";
+        return TW_E_BAD_PARAMETER;
+    }
+    TW_HIP(e, hipHostUnregister(hptr));
     return TW_OK;
 }
 
@@ -1814,6 +2024,9 @@ extern "C" int tw_debug_stamps(tw_engine* e, unsigned long long* out)
     return hipMemcpy(out, e->dbg_stamps, 64 * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 256 : 0;
 }
 
+// number of captured single-pair schedules this engine holds (tests: the graph path is really the one that ran)
+extern "C" int tw_debug_graphs(tw_engine* e) { return e ? (int)e->lat_graphs.size() : -1; }
+
 // occupancy report of the main kernels (workgroups per CU the runtime admits) — tools/kbench.py
 extern "C" int tw_debug_occupancy(char* buf, int cap)
 {
@@ -1825,10 +2038,12 @@ extern "C" int tw_debug_occupancy(char* buf, int cap)
         if (o > 0) n += o;
     };
     add("tw_blur_solve4<15,256>", (const void*)tw_blur_solve4<15, 256, 16, 8, true>, 256, 0);
+#ifdef TW_VARIANTS
     add("tw_blur_solve8<15,256>", (const void*)tw_blur_solve8<15, 256, 16, 8, true, true>, 256, 0);
     add("tw_blur_solve8<15,128>", (const void*)tw_blur_solve8<15, 128, 16, 8, true, true>, 128, 0);
     add("tw_polyexp<7>", (const void*)tw_polyexp<7>, 256, 0);
     add("tw_polyexp_pk<7,16>", (const void*)tw_polyexp_pk<7, 16>, 256, 0);
+#endif
     add("tw_polyexp_pk<7,8>", (const void*)tw_polyexp_pk<7, 8>, 256, 0);
     add("tw_update_matrices<true,2>", (const void*)tw_update_matrices<true, 2>, 256, 0);
     add("tw_pyr_k3<0>", (const void*)tw_pyr_k3<0>, 256, 0);

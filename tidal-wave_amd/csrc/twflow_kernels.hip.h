@@ -748,6 +748,7 @@ struct PolyArgs {
     PolyCoef c;
 };
 
+#ifdef TW_VARIANTS  // A/B kernel (TW_POLY_VARIANT=0): only in `make VARIANTS=1` builds (libtwflow_variants.so)
 template <int N>
 __global__ __launch_bounds__(256) void tw_polyexp(PolyArgs a)
 {
@@ -852,6 +853,8 @@ __global__ __launch_bounds__(256) void tw_polyexp(PolyArgs a)
     }
 }
 
+#endif  // TW_VARIANTS
+
 // -----------------------------------------------------------------------------------------------------
 // tw_polyexp_pk<N> : the same arithmetic with every float add/sub/mul issued as a packed-f32 instruction
 //   (v_pk_add_f32 / v_pk_mul_f32 do two lanes' worth of IEEE f32 work in one issue slot; no contraction, so the
@@ -865,7 +868,10 @@ __global__ __launch_bounds__(256) void tw_polyexp(PolyArgs a)
 //         planes are processed one after the other (moment 0 -> b1,b4,b2; moment 1 -> b3,b6; moment 2 -> b5) so
 //         that one window and at most 12 double accumulators are live
 // -----------------------------------------------------------------------------------------------------
-template <int N, int TH>
+// F32ACC = true is a MEASUREMENT variant only (engine option TW_OPT_POLYEXP_F32, never the default): the horizontal
+// accumulators b1..b6 are float instead of the CPU code's double — what OpenCV's own CUDA kernel does.  Not bit-exact;
+// exists to put a number on "what would polyexp cost without the f64 half" (profiles/r03_polyexp_f32.md).
+template <int N, int TH, bool F32ACC = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) void tw_polyexp_pk(PolyArgs a)
 {
     constexpr int RP = TH / 2, NW = TH + 2 * N, NPA = NW / 2, NPB = NW / 2 - 1;
@@ -932,6 +938,55 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
             }
         };
         f32x2 o[5][2];    // [plane][row q] = {pixel 0, pixel 1}
+        if constexpr (F32ACC) {
+            // all-float horizontal pass, packed over the row pair; same tap order as the double version
+            const float ig11 = (float)c.ig11, ig03 = (float)c.ig03, ig33 = (float)c.ig33, ig55 = (float)c.ig55;
+            f32x2 p03f[2];
+            load_window(0);
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const int li = PE_HALO + j;
+                f32x2 b1 = v[li] * c.g[0], b2 = f32x2{0.f, 0.f}, b4 = f32x2{0.f, 0.f};
+#pragma unroll
+                for (int k = 1; k <= N; k++) {
+                    const f32x2 tg = v[li + k] + v[li - k];
+                    const f32x2 dd = v[li + k] - v[li - k];
+                    b1 = b1 + tg * c.g[k];
+                    b4 = b4 + tg * c.xxg[k];
+                    b2 = b2 + dd * c.xg[k];
+                }
+                p03f[j] = b1 * ig03;
+                const f32x2 r1 = b2 * ig11, r3 = p03f[j] + b4 * ig33;
+                o[1][0][j] = r1[0]; o[1][1][j] = r1[1];
+                o[3][0][j] = r3[0]; o[3][1][j] = r3[1];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            load_window(1);
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const int li = PE_HALO + j;
+                f32x2 b3 = v[li] * c.g[0], b6 = f32x2{0.f, 0.f};
+#pragma unroll
+                for (int k = 1; k <= N; k++) {
+                    b3 = b3 + (v[li + k] + v[li - k]) * c.g[k];
+                    b6 = b6 + (v[li + k] - v[li - k]) * c.xg[k];
+                }
+                const f32x2 r0 = b3 * ig11, r4 = b6 * ig55;
+                o[0][0][j] = r0[0]; o[0][1][j] = r0[1];
+                o[4][0][j] = r4[0]; o[4][1][j] = r4[1];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            load_window(2);
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const int li = PE_HALO + j;
+                f32x2 b5 = v[li] * c.g[0];
+#pragma unroll
+                for (int k = 1; k <= N; k++) b5 = b5 + (v[li + k] + v[li - k]) * c.g[k];
+                const f32x2 r2 = p03f[j] + b5 * ig33;
+                o[2][0][j] = r2[0]; o[2][1][j] = r2[1];
+            }
+        } else {
         double p03[2][2];  // b1*ig03 of [pixel][row]
         // (the two pixels and the two rows advance in lockstep, one tap at a time: 12 independent f64 chains)
         // moment 0: b1, b4, b2
@@ -1044,6 +1099,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
 #pragma unroll
                 for (int q = 0; q < 2; q++) o[2][q][j] = (float)(p03[j][q] + b5[j][q] * c.ig33);
         }
+        }  // !F32ACC
         // every result is materialised here: left alone, LLVM sinks the chains of the second row / second pixel into
         // the edge conditionals below (their halves of every packed value then wait in scratch)
 #pragma unroll
@@ -1540,6 +1596,7 @@ __global__ __launch_bounds__(COLS) __attribute__((amdgpu_waves_per_eu(4, 8))) vo
     }
 }
 
+#ifdef TW_VARIANTS  // A/B kernel (TW_BLUR_VARIANT=60/61, measured 18-68 % slower): VARIANTS=1 builds only
 // -----------------------------------------------------------------------------------------------------
 // tw_blur_solve6<MH,COLS,HALO,TH> : tw_blur_solve4's arithmetic as a PLANE PIPELINE (VERDICT r1 #5 / DESIGN §9 (a)):
 //   the five M planes go one after the other through a two-plane LDS ring (16 KB instead of 40 KB), the horizontal
@@ -1700,6 +1757,8 @@ __global__ __launch_bounds__(COLS) __attribute__((amdgpu_waves_per_eu(WPE, 8))) 
     }
 }
 
+#endif  // TW_VARIANTS
+
 // -----------------------------------------------------------------------------------------------------
 // tw_blur_solve_pp<MH,COLS,HALO,TH> : the same arithmetic for SMALL grids (one pair, coarse levels), where a launch
 //   is a single round of workgroups and its duration is one workgroup's serial V -> H -> S chain, not throughput.
@@ -1831,6 +1890,7 @@ __global__ __launch_bounds__(5 * COLS) void tw_blur_solve_pp(BlurArgs a)
     }
 }
 
+#ifdef TW_VARIANTS  // A/B kernel (TW_BLUR_VARIANT=2, measured equal within the noise): VARIANTS=1 builds only
 // -----------------------------------------------------------------------------------------------------
 // tw_blur_solve4y<MH,COLS,HALO,TH,NSUB> : tw_blur_solve4 with NSUB vertically adjacent TH-row sub-tiles per workgroup.
 //   The vertical pass runs once over a TH*NSUB + 2*MH row register window (the window rows of adjacent sub-tiles
@@ -2000,6 +2060,8 @@ __global__ __launch_bounds__(COLS) __attribute__((amdgpu_waves_per_eu(4, 8))) vo
         subtile(std::true_type{}, y00 + TH);
     }
 }
+
+#endif  // TW_VARIANTS
 
 // -----------------------------------------------------------------------------------------------------
 // tw_blur_solve8<MH,COLS,HALO,TH,FUSED,PREFETCH> : v4's tiling and occupancy (COLS threads, 40 KB LDS, 4

@@ -2,6 +2,7 @@
 // list after a short sleep.  ONLY for the ThreadSanitizer build of the host layer (`make tsan`), which must run
 // on the CPU (GPU sanitizer runs are not available): it lets twhost.cpp's queue, consumers, pump and dispose path
 // run under TSAN with 8 consumers on 8 pretend devices.  Never linked into the product.
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -9,7 +10,9 @@
 #include <chrono>
 #include <map>
 #include <mutex>
+#include <string>
 #include <thread>
+#include <vector>
 
 #include "../../include/twflow.h"
 
@@ -31,6 +34,34 @@ int tw_device_count(void)
 {
     const char* ev = getenv("TW_STUB_DEVICES");
     return ev ? atoi(ev) : 8;
+}
+// TW_STUB_PCI="0000:01:00.0,0000:81:00.0,...": bus id of pretend device i (cycled); unset: "0000:<i>0:00.0"
+tw_status tw_device_pci_bus_id(int device, char* buf, int cap)
+{
+    if (!buf || cap < 16 || device < 0 || device >= tw_device_count()) return TW_E_DEVICE;
+    const char* ev = getenv("TW_STUB_PCI");
+    if (ev && ev[0]) {
+        std::string s(ev);
+        std::vector<std::string> ids;
+        size_t p = 0;
+        while (p <= s.size()) {
+            const size_t q = s.find(',', p);
+            ids.push_back(s.substr(p, q == std::string::npos ? std::string::npos : q - p));
+            if (q == std::string::npos) break;
+            p = q + 1;
+        }
+        snprintf(buf, (size_t)cap, "%s", ids[(size_t)device % ids.size()].c_str());
+    } else {
+        snprintf(buf, (size_t)cap, "0000:%x0:00.0", device & 0xf);
+    }
+    return TW_OK;
+}
+tw_status tw_prof_select(tw_engine*, int, int) { return TW_OK; }
+tw_status tw_prof_read(tw_engine*, int, double* ms, int* n)
+{
+    if (ms) *ms = 0;
+    if (n) *n = 0;
+    return TW_OK;
 }
 const char* tw_strerror(tw_status) { return "stub"; }
 const char* tw_last_error(const tw_engine*) { return ""; }

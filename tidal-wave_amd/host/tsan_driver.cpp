@@ -5,6 +5,7 @@
 // report = pass (tests/test_host_tsan.py).
 #include <stdio.h>
 
+#include <chrono>
 #include <condition_variable>
 #include <mutex>
 #include <thread>
@@ -58,6 +59,16 @@ int main()
         Manager* mg = new Manager(observer(s));
         mg->start(p);
         if (mg->consumerCount() != 8) { fprintf(stderr, "expected 8 consumers, got %d\n", mg->consumerCount()); rc = 1; }
+        mg->waitReady();
+        mg->markEpoch();  // the readiness / epoch / stats paths of the queue driver, raced against the producers below
+        std::thread watcher([&] {
+            for (int i = 0; i < 200; i++) {
+                long n = 0;
+                for (const ConsumerStats& cs : mg->consumerStats()) n += cs.pairs;
+                if (n > 1008) { fprintf(stderr, "stats: %ld pairs\n", n); rc = 1; }
+                std::this_thread::sleep_for(std::chrono::microseconds(200));
+            }
+        });
         const int N = 1000, BAD = 7;
         auto producer = [&](int lo, int hi) {
             for (int j = lo; j < hi; j++) {
@@ -75,6 +86,7 @@ int main()
         mg->request("", "x");
         t1.join();
         t2.join();
+        watcher.join();
         {
             std::unique_lock<std::mutex> lk(s.m);
             s.cv.wait(lk, [&] { return s.data + s.err >= N + BAD + 1; });

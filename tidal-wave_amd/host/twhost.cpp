@@ -8,9 +8,113 @@
 #include <string.h>
 #include <zlib.h>
 
+#include <sched.h>
+
 #include <algorithm>
+#include <fstream>
+#include <sstream>
 
 namespace twhost {
+
+// ---------------------------------------------------------------------------------------------------
+// progress prints of the reference (std::cout in src/manager.cpp:74, src/consumer.cpp:49,55,92), behind TW_LOG
+// (the reference's own CLI had to dup2 stdout away to hide them).  TW_LOG=1: stdout like the
+// reference, TW_LOG=2: stderr.
+// ---------------------------------------------------------------------------------------------------
+static FILE* log_stream()
+{
+    static FILE* f = [] {
+        const char* ev = getenv("TW_LOG");
+        const int v = ev ? atoi(ev) : 0;
+        return v == 1 ? stdout : (v >= 2 ? stderr : (FILE*)nullptr);
+    }();
+    return f;
+}
+#define TW_LOGF(...)                      \
+    do {                                  \
+        if (FILE* lf_ = log_stream()) {   \
+            fprintf(lf_, __VA_ARGS__);    \
+            fflush(lf_);                  \
+        }                                 \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------------
+// NUMA placement (SURVEY.md 8(e) "scaling risks": pin each worker + its staging buffers to the GPU's NUMA node)
+// ---------------------------------------------------------------------------------------------------
+static std::string sysfs_root()
+{
+    const char* ev = getenv("TW_SYSFS_ROOT");
+    return ev && ev[0] ? std::string(ev) : std::string("/sys");
+}
+
+static bool read_first_line(const std::string& path, std::string& out)
+{
+    std::ifstream f(path);
+    if (!f) return false;
+    std::getline(f, out);
+    return true;
+}
+
+// "0-3,8,10-11" -> {0,1,2,3,8,10,11}
+static std::vector<int> parse_cpulist(const std::string& s)
+{
+    std::vector<int> v;
+    std::stringstream ss(s);
+    std::string tok;
+    while (std::getline(ss, tok, ',')) {
+        if (tok.empty()) continue;
+        const size_t dash = tok.find('-');
+        const int a = atoi(tok.c_str());
+        const int b = dash == std::string::npos ? a : atoi(tok.c_str() + dash + 1);
+        for (int c = a; c <= b && c < CPU_SETSIZE; c++)
+            if (c >= 0) v.push_back(c);
+    }
+    return v;
+}
+
+bool numa_cpus_of_device(int device, std::string* busid, int* node, std::vector<int>* cpus)
+{
+    char id[32];
+    if (tw_device_pci_bus_id(device, id, (int)sizeof(id)) != TW_OK || !id[0]) return false;
+    if (busid) *busid = id;
+    std::string line;
+    if (!read_first_line(sysfs_root() + "/bus/pci/devices/" + id + "/numa_node", line)) return false;
+    const int n = atoi(line.c_str());
+    if (node) *node = n;
+    if (n < 0) return false;  // the platform reports no NUMA affinity for this device
+    if (!read_first_line(sysfs_root() + "/devices/system/node/node" + std::to_string(n) + "/cpulist", line)) return false;
+    std::vector<int> v = parse_cpulist(line);
+    if (v.empty()) return false;
+    if (cpus) *cpus = std::move(v);
+    return true;
+}
+
+std::vector<int> this_thread_cpus()
+{
+    std::vector<int> v;
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof(set), &set) != 0) return v;
+    for (int c = 0; c < CPU_SETSIZE; c++)
+        if (CPU_ISSET(c, &set)) v.push_back(c);
+    return v;
+}
+
+bool bind_this_thread(const std::vector<int>& cpus)
+{
+    cpu_set_t allowed, want;
+    CPU_ZERO(&allowed);
+    CPU_ZERO(&want);
+    if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return false;
+    int n = 0;
+    for (int c : cpus)
+        if (c >= 0 && c < CPU_SETSIZE && CPU_ISSET(c, &allowed)) {
+            CPU_SET(c, &want);
+            n++;
+        }
+    if (n == 0) return false;  // e.g. a container whose CPU share lies on another node: stay where we are
+    return sched_setaffinity(0, sizeof(want), &want) == 0;
+}
 
 // ---------------------------------------------------------------------------------------------------
 // image files -> 8-bit gray  (cv::imread(path, IMREAD_GRAYSCALE), src/opticalflow.cpp:37,44)
@@ -267,9 +371,9 @@ void resize_u8_linear(const std::vector<uint8_t>& src, int sw, int sh, std::vect
 // Consumer
 // ---------------------------------------------------------------------------------------------------
 Consumer::Consumer(int id, MessageQueue<Request>& req, MessageQueue<Response>& res, const tw_params& p, int batch,
-                   int decode_threads, int n_consumers)
+                   int decode_threads, int n_consumers, ConsumerShared* shared)
     : id_(id), req_(req), res_(res), params_(p), batch_(std::max(1, batch)), decode_threads_(std::max(1, decode_threads)),
-      n_consumers_(std::max(1, n_consumers))
+      n_consumers_(std::max(1, n_consumers)), shared_(shared)
 {
 }
 Consumer::~Consumer() { join(); }
@@ -340,14 +444,58 @@ void Consumer::run()
     // device binding happens here, on the worker thread (the reference binds on the main thread:
     // src/consumer.cpp:22 via src/manager.cpp:56 — SURVEY.md Appendix B#6)
     const int ndev = tw_device_count();
+    const int dev = ndev > 0 ? id_ % ndev : -1;
+    ConsumerStats mine;  // this thread's own counters; published under the shared mutex
+    mine.id = id_;
+    mine.device = dev;
+    // NUMA placement BEFORE the engine exists: the thread — and with it the decode pool it spawns and, by first touch,
+    // the page-locked staging / result buffers tw_engine_create and tw_submit_u8 allocate — moves to the CPUs of the
+    // GPU's node, so that 8 consumers x ~16 GB/s of pinned H2D do not cross the socket link.  TW_NUMA=0 disables.
+    {
+        const char* ev = getenv("TW_NUMA");
+        const bool on = !ev || atoi(ev) != 0;
+        std::vector<int> cpus;
+        int node = -1;
+        if (dev >= 0 && numa_cpus_of_device(dev, &mine.pciBusId, &node, &cpus) && on && bind_this_thread(cpus))
+            mine.numaNode = node;
+        mine.cpus = this_thread_cpus();
+    }
     tw_engine* eng = nullptr;
     std::string eng_err;
     if (ndev > 0) {
-        tw_status r = tw_engine_create(id_ % ndev, &params_, batch_, &eng);
+        tw_status r = tw_engine_create(dev, &params_, batch_, &eng);
         if (r != TW_OK) eng_err = std::string("engine: ") + tw_strerror(r);
     } else {
         eng_err = "no HIP device available";
     }
+    const bool prof = eng && shared_ && shared_->profile;
+    if (prof) {
+        (void)tw_prof_select(eng, TW_K_BLUR_SOLVE, 0);
+        (void)tw_prof_select(eng, TW_K_POLYEXP, 0);
+    }
+    int my_epoch = shared_ ? shared_->epoch.load() : 0;
+    auto publish = [&] {
+        if (!shared_) return;
+        std::lock_guard<std::mutex> lk(shared_->m);
+        if ((size_t)id_ < shared_->stats.size()) shared_->stats[(size_t)id_] = mine;
+        shared_->cv.notify_all();
+    };
+    // kernel events are read (a device synchronise) only when nothing of ours is in flight
+    auto read_prof = [&](bool keep) {
+        if (!prof) return;
+        static const int kc[2] = {TW_K_BLUR_SOLVE, TW_K_POLYEXP};
+        for (int i = 0; i < 2; i++) {
+            double ms = 0;
+            int n = 0;
+            if (tw_prof_read(eng, kc[i], &ms, &n) == TW_OK && keep) {
+                mine.profMs[i] += ms;
+                mine.profLaunches[i] += n;
+            }
+        }
+    };
+    mine.ready = true;
+    mine.engineError = eng_err;
+    publish();
     // wait for one job and hand its response to the pump
     auto finish = [&](Staged& s) {
         if (s.done) return;
@@ -379,6 +527,9 @@ void Consumer::run()
             res.status = "ERROR";  // src/consumer.cpp:85-88
             res.reason = s.err;
         }
+        TW_LOGF("finish optical flow: %g\n", (double)res.time);  // src/consumer.cpp:55
+        mine.pairs++;
+        publish();  // before the response leaves: whoever has seen N responses sees N pairs in the stats
         res_.push(std::move(res));
     };
     // Two batches are kept going: the one just submitted computes while the next one is popped, decoded and
@@ -393,7 +544,18 @@ void Consumer::run()
         Request first;
         if (!req_.tryPopNow(first)) {
             finish_all(prev);  // nothing queued: deliver what is outstanding before blocking
+            read_prof(true);   // idle: nothing of ours is in flight, so the event read's synchronise costs nothing
+            publish();
             if (!req_.tryPop(first)) break;
+        }
+        if (shared_ && shared_->epoch.load() != my_epoch) {
+            // Manager::markEpoch(): counters restart here (the manager marks an epoch only while the queue is empty
+            // and every response has arrived, so nothing of this consumer is in flight)
+            my_epoch = shared_->epoch.load();
+            read_prof(false);
+            mine.pairs = mine.batches = 0;
+            mine.profMs[0] = mine.profMs[1] = 0;
+            mine.profLaunches[0] = mine.profLaunches[1] = 0;
         }
         std::vector<Staged> jobs(1);
         jobs[0].req = std::move(first);
@@ -406,6 +568,10 @@ void Consumer::run()
             jobs.emplace_back();
             jobs.back().req = std::move(more);
         }
+        if (log_stream())
+            for (const Staged& s : jobs)  // src/consumer.cpp:49
+                TW_LOGF("consume: %s <-> %s\n", s.req.expect_image.c_str(), s.req.target_image.c_str());
+        mine.batches++;
         // decode pool: once the flow runs on the GPU the two imreads of a pair are > 99 % of the wall time
         // (SURVEY §8 f1), so the pairs of a batch are decoded side by side
         {
@@ -453,7 +619,10 @@ void Consumer::run()
         prev = std::move(jobs);
     }
     finish_all(prev);
+    read_prof(true);
+    publish();
     if (eng) tw_engine_destroy(eng);
+    TW_LOGF("finish consumer%d\n", id_);  // src/consumer.cpp:92
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -485,12 +654,32 @@ void Manager::start(const Parameter& p)
     int dec = 0;
     if (const char* ev = getenv("TW_DECODE_THREADS")) dec = atoi(ev);
     if (dec <= 0) dec = std::max(1, std::min(16, (int)std::thread::hardware_concurrency() / n));
+    shared_.profile = p.profileKernels;
+    shared_.stats.assign((size_t)n, ConsumerStats());
     for (int i = 0; i < n; i++) {
-        consumers_.push_back(new Consumer(i, requestQueue_, responseQueue_, p.optParam, batch, dec, n));
+        consumers_.push_back(new Consumer(i, requestQueue_, responseQueue_, p.optParam, batch, dec, n, &shared_));
         consumers_.back()->start();
     }
     pump_ = std::thread([this] { work(); });
 }
+
+void Manager::waitReady()
+{
+    std::unique_lock<std::mutex> lk(shared_.m);
+    shared_.cv.wait(lk, [&] {
+        for (const ConsumerStats& s : shared_.stats)
+            if (!s.ready) return false;
+        return true;
+    });
+}
+
+std::vector<ConsumerStats> Manager::consumerStats()
+{
+    std::lock_guard<std::mutex> lk(shared_.m);
+    return shared_.stats;
+}
+
+void Manager::markEpoch() { shared_.epoch++; }
 
 int Manager::request(const std::string& expect_image, const std::string& target_image)
 {
@@ -499,6 +688,7 @@ int Manager::request(const std::string& expect_image, const std::string& target_
     r.target_image = target_image;
     r.span = param_.span;
     r.threshold = param_.threshold;
+    TW_LOGF("request: %s <-> %s\n", expect_image.c_str(), target_image.c_str());  // src/manager.cpp:74
     {
         std::lock_guard<std::mutex> lk(report_m_);
         report_.requestCount++;

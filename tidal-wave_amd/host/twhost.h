@@ -60,7 +60,36 @@ struct Parameter {
     // batch of a consumer (0: 32).  The consumer count is min(numThreads, devices * perDevice).
     int consumersPerDevice = 0;
     int batch = 0;
+    // bracket the level-0 window-average and polynomial-expansion launches of every consumer's engine with events
+    // (tw_prof_select): the queue driver's roofline figures come from them (tools/bench_queue.cpp)
+    bool profileKernels = false;
 };
+
+// What one consumer did, as seen by Manager::consumerStats() (a copy; the consumer thread owns the original).
+struct ConsumerStats {
+    int id = 0;
+    int device = -1;          // id % deviceCount, -1 without a HIP device
+    bool ready = false;       // the engine exists (or could not be created: engineError says why)
+    std::string engineError;
+    long pairs = 0;           // responses pushed since the last Manager::markEpoch()
+    long batches = 0;         // engine batches submitted since then
+    // event-bracketed level-0 launches since then: [0] window average + solve, [1] polynomial expansion
+    double profMs[2] = {0, 0};
+    int profLaunches[2] = {0, 0};
+    // placement of the consumer thread (and, by inheritance / first touch, of its decode pool and of the page-locked
+    // buffers its engine allocates): NUMA node of the GPU, -1 = not bound (TW_NUMA=0, no NUMA information, or none
+    // of the node's CPUs is available to this process)
+    std::string pciBusId;
+    int numaNode = -1;
+    std::vector<int> cpus;    // CPUs the consumer thread may run on after placement
+};
+
+// NUMA node and CPU list of a device from sysfs: /sys/bus/pci/devices/<bus id>/numa_node and
+// /sys/devices/system/node/node<N>/cpulist (TW_SYSFS_ROOT replaces "/sys": tests).  false: unknown.
+bool numa_cpus_of_device(int device, std::string* busid, int* node, std::vector<int>* cpus);
+// Restrict the calling thread to `cpus` (those of them this process may use); false if none is usable.
+bool bind_this_thread(const std::vector<int>& cpus);
+std::vector<int> this_thread_cpus();
 
 // Blocking MPMC queue, MessageQueue<T> of src/message_queue.h:50-118 (stop() wakes every waiter; as in the
 // reference, items still queued at stop() are dropped — Appendix B#8 of SURVEY.md).
@@ -132,10 +161,19 @@ struct Observer {
 // Consumer (src/consumer.{h,cpp}): one worker thread bound to one GPU; pulls requests, runs the engine, pushes
 // responses.  Consumer i uses device i % deviceCount; with no HIP device every job answers ERROR (the engine
 // has no CPU path).
+// state shared between the Manager and its consumers
+struct ConsumerShared {
+    std::mutex m;
+    std::condition_variable cv;
+    std::vector<ConsumerStats> stats;  // [consumer id]
+    std::atomic<int> epoch{0};
+    bool profile = false;
+};
+
 class Consumer {
 public:
     Consumer(int id, MessageQueue<Request>& req, MessageQueue<Response>& res, const tw_params& p, int batch,
-             int decode_threads, int n_consumers = 1);
+             int decode_threads, int n_consumers = 1, ConsumerShared* shared = nullptr);
     ~Consumer();
     void start();
     void join();
@@ -149,6 +187,7 @@ private:
     int batch_;
     int decode_threads_;  // images of a batch are decoded by this many threads
     int n_consumers_;     // consumers on the same request queue: a consumer leaves the others their share of a short queue
+    ConsumerShared* shared_;
     std::thread th_;
 };
 
@@ -163,6 +202,13 @@ public:
     // the same for an in-memory pair (see RawPair); the two names are only echoed in the response
     int requestRaw(const std::string& expect_name, const std::string& target_name, const RawPair& raw);
     int consumerCount() const { return (int)consumers_.size(); }
+    // blocks until every consumer has bound its device and created its engine (or failed to)
+    void waitReady();
+    // snapshot of what every consumer did since the last markEpoch()
+    std::vector<ConsumerStats> consumerStats();
+    // every consumer zeroes its counters (and discards its pending kernel events) before the next job it takes;
+    // call while the queue is empty and every response has arrived
+    void markEpoch();
     void stop();  // idempotent; completion is reported through onCompleted
     bool running() const { return running_; }
 
@@ -178,6 +224,7 @@ private:
     std::atomic<bool> stopped_{false};
     Report report_;
     std::mutex report_m_;
+    ConsumerShared shared_;
 };
 
 }  // namespace twhost

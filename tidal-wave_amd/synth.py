@@ -56,6 +56,12 @@ def make_expect(rng, h, w):
 
 
 def warp(expect, rng):
+    return warp_with_flow(expect, rng)[0]
+
+
+def warp_with_flow(expect, rng):
+    """(target, vx, vy): target(x, y) = expect(x - vx, y - vy), bilinear; the flow a perfect estimator would report at
+    (x, y) for the pair (expect, target) is ~(vx, vy) there (exactly v at the matched position; v is smooth)."""
     h, w = expect.shape
     yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
     vx = np.zeros((h, w))
@@ -76,16 +82,18 @@ def warp(expect, rng):
     fy = sy - y0
     e = expect.astype(np.float64)
     out = (e[y0, x0] * (1 - fx) + e[y0, x1] * fx) * (1 - fy) + (e[y1, x0] * (1 - fx) + e[y1, x1] * fx) * fy
-    return np.clip(np.rint(out), 0, 255).astype(np.uint8)
+    return np.clip(np.rint(out), 0, 255).astype(np.uint8), vx, vy
 
 
-def make_pair(index, h=1080, w=1920, kind=None):
-    """Returns (expect, target) uint8 [h,w]."""
+def make_pair(index, h=1080, w=1920, kind=None, with_flow=False):
+    """Returns (expect, target) uint8 [h,w]; with_flow: (expect, target, vx, vy) for the warped kinds (0, 1)."""
     rng = np.random.default_rng(BASE_SEED + index)
     expect = make_expect(rng, h, w)
     k = index % 4 if kind is None else kind
     if k in (0, 1):
-        target = warp(expect, rng)
+        target, vx, vy = warp_with_flow(expect, rng)
+        if with_flow:
+            return expect, target, vx, vy
     elif k == 2:
         target = expect.copy()
         rw, rh = max(w // 4, 4), max(h // 5, 4)

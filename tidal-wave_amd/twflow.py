@@ -45,15 +45,20 @@ _lib = None
 
 # every symbol include/twflow.h declares
 OPT_SCAN_FUSED_FINAL = 1
+OPT_POLYEXP_F32 = 2
 
 SYMBOLS = [
-    "tw_default_params", "tw_device_count", "tw_engine_create", "tw_engine_destroy", "tw_strerror",
+    "tw_default_params", "tw_has_variants", "tw_device_count", "tw_device_pci_bus_id", "tw_engine_create", "tw_engine_destroy", "tw_strerror",
     "tw_last_error", "tw_flow_u8", "tw_diff_u8", "tw_submit_u8", "tw_submit_dev", "tw_flush", "tw_wait",
-    "tw_grid_capacity", "tw_dev_alloc", "tw_dev_free", "tw_dev_upload", "tw_host_alloc", "tw_host_free", "tw_set_option",
+    "tw_grid_capacity", "tw_dev_alloc", "tw_dev_free", "tw_dev_upload", "tw_host_alloc", "tw_host_free", "tw_host_register", "tw_host_unregister", "tw_set_option",
     "tw_prof_select", "tw_prof_read",
     "tw_algorithmic_bytes", "tw_algorithmic_bytes_pair", "tw_min_traffic_bytes_pair", "tw_num_levels", "tw_level_chunk", "tw_bench_stage", "tw_stage_pyr_level",
     "tw_stage_polyexp", "tw_stage_update_matrices", "tw_stage_flow_upsample_update", "tw_stage_blur_solve",
 ]
+
+
+VARIANTS_LIB_PATH = os.path.join(_HERE, "libtwflow_variants.so")
+_variants = None
 
 
 def lib():
@@ -63,11 +68,37 @@ def lib():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise ImportError("libtwflow.so not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
-    L = C.CDLL(LIB_PATH)
+    _lib = _bind(LIB_PATH)
+    return _lib
+
+
+class use_variants_library:
+    """Context manager: engines created inside use libtwflow_variants.so (`make VARIANTS=1`: the product library plus
+    the measured-slower A/B kernels behind TW_BLUR_VARIANT / TW_POLY_VARIANT / TW_BLUR_SMALL / TW_UPD_NY).  Tests and
+    tools only; the product library refuses those switches."""
+
+    def __enter__(self):
+        global _lib, _variants
+        if _variants is None:
+            if not os.path.exists(VARIANTS_LIB_PATH):
+                raise ImportError("libtwflow_variants.so not built: make -C tidal-wave_amd/csrc VARIANTS=1")
+            _variants = _bind(VARIANTS_LIB_PATH)
+        self._saved = lib()
+        _lib = _variants
+        return _variants
+
+    def __exit__(self, *a):
+        global _lib
+        _lib = self._saved
+
+
+def _bind(path):
+    L = C.CDLL(path)
     vp, fp, u8p, ip = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_uint8), C.POINTER(C.c_int)
     L.tw_default_params.argtypes = [C.POINTER(Params)]
     L.tw_default_params.restype = None
     L.tw_device_count.restype = C.c_int
+    L.tw_device_pci_bus_id.argtypes = [C.c_int, C.c_char_p, C.c_int]
     L.tw_engine_create.argtypes = [C.c_int, C.POINTER(Params), C.c_int, C.POINTER(vp)]
     L.tw_engine_destroy.argtypes = [vp]
     L.tw_engine_destroy.restype = None
@@ -92,6 +123,8 @@ def lib():
     L.tw_dev_upload.argtypes = [vp, vp, vp, C.c_size_t]
     L.tw_host_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
     L.tw_host_free.argtypes = [vp, vp]
+    L.tw_host_register.argtypes = [vp, vp, C.c_size_t]
+    L.tw_host_unregister.argtypes = [vp, vp]
     L.tw_set_option.argtypes = [vp, C.c_int, C.c_int]
     L.tw_prof_select.argtypes = [vp, C.c_int, C.c_int]
     L.tw_prof_read.argtypes = [vp, C.c_int, C.POINTER(C.c_double), ip]
@@ -107,7 +140,9 @@ def lib():
     L.tw_stage_update_matrices.argtypes = [vp, fp, fp, fp, C.c_int, C.c_int, fp]
     L.tw_stage_flow_upsample_update.argtypes = [vp, fp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, fp, fp]
     L.tw_stage_blur_solve.argtypes = [vp, fp, fp, fp, C.c_int, C.c_int, C.c_int, fp, fp]
-    _lib = L
+    L.tw_has_variants.restype = C.c_int
+    L.tw_debug_graphs.argtypes = [vp]
+    L.tw_debug_graphs.restype = C.c_int
     return L
 
 
@@ -121,6 +156,14 @@ def default_params(**kw):
 
 def device_count():
     return lib().tw_device_count()
+
+
+def device_pci_bus_id(device):
+    buf = C.create_string_buffer(32)
+    rc = lib().tw_device_pci_bus_id(device, buf, 32)
+    if rc != TW_OK:
+        raise TwError(rc, "no such device")
+    return buf.value.decode()
 
 
 def grid_capacity(w, h, span):

@@ -9,13 +9,14 @@
 // uses every device the box has.
 //
 //   bench_queue --pgm-dir DIR [--pairs 2048] [--devices 0] [--per-device 1] [--batch 128] [--warmup-batches 2]
-//               [--pinned 1] [--files 0] [--span 10] [--threshold 5]
+//               [--pinned 1] [--files 0] [--span 10] [--threshold 5] [--prof 1]
 // DIR holds pair_<i>_a.pgm / pair_<i>_b.pgm (i = 0..), written by bench.py / tests from tidal-wave_amd/synth.py.
 // Prints one JSON line.
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -31,6 +32,7 @@ namespace {
 struct Args {
     std::string dir;
     int pairs = 2048, devices = 0, per_device = 1, batch = 128, warmup_batches = 2, pinned = 1, files = 0, span = 10;
+    int prof = 1;  // event-bracket the level-0 blur / polyexp launches of every consumer's engine
     double threshold = 5.0;
 };
 
@@ -51,6 +53,7 @@ bool parse(int argc, char** argv, Args& a)
         else if ((v = val("--pinned"))) a.pinned = atoi(v);
         else if ((v = val("--files"))) a.files = atoi(v);
         else if ((v = val("--span"))) a.span = atoi(v);
+        else if ((v = val("--prof"))) a.prof = atoi(v);
         else if ((v = val("--threshold"))) a.threshold = atof(v);
         else {
             fprintf(stderr, "unknown argument %s\n", argv[i]);
@@ -168,9 +171,14 @@ int main(int argc, char** argv)
     p.consumersPerDevice = std::max(1, a.per_device);
     p.numThreads = ndev * p.consumersPerDevice;  // one consumer per (device, slot): src/manager.cpp:55-59
     p.batch = a.batch;
+    p.profileKernels = a.prof != 0;
     Manager* mg = new Manager(obs);
     mg->start(p);
     const int consumers = mg->consumerCount();
+    // Readiness barrier: every consumer has bound its device, placed itself on the GPU's NUMA node and
+    // created its engine before the first job is pushed — HIP initialisation is serialised per process, and a
+    // consumer still inside tw_engine_create would otherwise pay for it inside the timed region.
+    mg->waitReady();
 
     auto push = [&](long j) {
         const int k = (int)(j % distinct);
@@ -192,11 +200,25 @@ int main(int argc, char** argv)
         cv.wait(lk, [&] { return done >= target; });
     };
 
-    // warm-up: every consumer builds its engine, plan and workspaces
-    const long warm = (long)a.warmup_batches * a.batch * consumers;
-    for (long j = 0; j < warm; j++) push(j);
-    wait_done(warm);
+    // warm-up: rounds of batch x consumers jobs until EVERY consumer has run at least warmup_batches full batches'
+    // worth of pairs (plan, workspaces, first-launch costs); a consumer that got none in a round gets its chance in
+    // the next one (a consumer takes at most its share of a short queue)
+    long warm = 0;
+    int rounds = 0;
+    const long want_each = (long)std::max(0, a.warmup_batches) * a.batch;  // 0: no warm-up at all (tests)
+    for (; rounds < 32; rounds++) {
+        long least = want_each;
+        for (const ConsumerStats& cs : mg->consumerStats()) least = std::min(least, cs.pairs);
+        if (least >= want_each) break;
+        const long n = (long)a.batch * consumers;
+        for (long j = 0; j < n; j++) push(warm + j);
+        warm += n;
+        wait_done(warm);
+    }
+    bool all_warm = true;
+    for (const ConsumerStats& cs : mg->consumerStats()) all_warm = all_warm && cs.pairs >= want_each;
     const long flagged_warm = flagged;
+    mg->markEpoch();  // every consumer restarts its counters (and drops the warm-up's kernel events) at its next job
 
     const auto t0 = std::chrono::steady_clock::now();
     for (long j = 0; j < a.pairs; j++) push(warm + j);
@@ -208,6 +230,7 @@ int main(int argc, char** argv)
         std::unique_lock<std::mutex> lk(m);
         cv.wait(lk, [&] { return completed; });
     }
+    const std::vector<ConsumerStats> stats = mg->consumerStats();  // the consumers have joined: final numbers
     delete mg;
     if (alloc_eng) {
         for (Img& im : imgs) tw_host_free(alloc_eng, im.data);
@@ -216,10 +239,20 @@ int main(int argc, char** argv)
     printf("{\"pairs\": %d, \"seconds\": %.6f, \"pairs_per_s\": %.2f, \"devices\": %d, \"consumers\": %d, "
            "\"engine_batch\": %d, \"distinct_pairs\": %d, \"width\": %d, \"height\": %d, \"input\": \"%s\", "
            "\"errors\": %ld, \"flagged_vectors\": %ld, \"report\": {\"request\": %d, \"data\": %d, \"error\": %d}, "
-           "\"first_error\": \"%s\"}\n",
+           "\"first_error\": \"%s\", \"warmup_pairs\": %ld, \"warmup_rounds\": %d, \"all_consumers_warm\": %s, "
+           "\"per_consumer\": [",
            a.pairs, sec, a.pairs / sec, ndev, consumers, a.batch, distinct, imgs[0].w, imgs[0].h,
            a.files ? "pgm files" : (a.pinned ? "page-locked host buffers" : "pageable host buffers"), errors,
            flagged - flagged_warm, final_report.requestCount, final_report.dataCount, final_report.errorCount,
-           first_error.c_str());
+           first_error.c_str(), warm, rounds, all_warm ? "true" : "false");
+    for (size_t i = 0; i < stats.size(); i++) {
+        const ConsumerStats& cs = stats[i];
+        printf("%s{\"id\": %d, \"device\": %d, \"pci\": \"%s\", \"numa_node\": %d, \"cpus\": %zu, \"pairs\": %ld, "
+               "\"batches\": %ld, \"blur_l0_ms\": %.4f, \"blur_l0_launches\": %d, \"polyexp_l0_ms\": %.4f, "
+               "\"polyexp_l0_launches\": %d}",
+               i ? ", " : "", cs.id, cs.device, cs.pciBusId.c_str(), cs.numaNode, cs.cpus.size(), cs.pairs, cs.batches,
+               cs.profMs[0], cs.profLaunches[0], cs.profMs[1], cs.profLaunches[1]);
+    }
+    printf("]}\n");
     return errors ? 1 : 0;
 }
