@@ -78,7 +78,7 @@ int main() {
 ''')
     exe = os.path.join(HOST, "build", "share_probe")
     r = subprocess.run(["g++", "-O1", "-std=c++17", "-o", exe, src, os.path.join(HOST, "stub_twflow.cpp"),
-                        os.path.join(HOST, "twhost.cpp"), os.path.join(HOST, "jpeg_gray.cpp"), "-lz", "-lpthread"],
+                        os.path.join(HOST, "twhost.cpp"), os.path.join(HOST, "jpeg_gray.cpp"), os.path.join(HOST, "tw_inflate.cpp"), "-lpthread"],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)

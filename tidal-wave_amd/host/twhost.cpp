@@ -1,17 +1,19 @@
 // twhost.cpp — see twhost.h.  Host-side only: file decode, size reconcile, queueing.  All pixel arithmetic of
 // the hot path happens in libtwflow.so (HIP); there is no CPU flow implementation here.
 #include "twhost.h"
+#include "tw_inflate.h"
 
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
-#include <zlib.h>
 
 #include <sched.h>
 
 #include <algorithm>
 #include <fstream>
+#include <memory>
+#include <new>
 #include <sstream>
 
 namespace twhost {
@@ -229,9 +231,13 @@ static bool decode_png(const std::vector<uint8_t>& d, std::vector<uint8_t>& img,
         const int ph = interlace ? (h - AY0[ps] + ADY[ps] - 1) / ADY[ps] : h;
         if (pw > 0 && ph > 0) total += (((size_t)pw * bpp_bits + 7) / 8 + 1) * (size_t)ph;
     }
-    std::vector<uint8_t> raw(total);
-    uLongf outlen = (uLongf)raw.size();
-    if (uncompress(raw.data(), &outlen, idat.data(), (uLong)idat.size()) != Z_OK || outlen != raw.size()) return false;
+    // (uninitialised: every byte is written by the inflate or the decode fails; + 8 bytes of slack for nothing — the
+    // decoder never writes past `total`)
+    std::unique_ptr<uint8_t[]> raw_buf(new (std::nothrow) uint8_t[total + 8]);
+    if (!raw_buf) return false;
+    uint8_t* const raw = raw_buf.get();
+    size_t outlen = 0;
+    if (!tw_inflate_zlib(idat.data(), idat.size(), raw, total, &outlen) || outlen != total) return false;
     img.resize((size_t)w * h);
     size_t pass_off = 0;
     const int W = w, H = h;  // the loops below run over one pass: w/h are its dimensions
@@ -242,40 +248,17 @@ static bool decode_png(const std::vector<uint8_t>& d, std::vector<uint8_t>& img,
     if (w <= 0 || h <= 0) continue;
     const size_t rowbytes = ((size_t)w * bpp_bits + 7) / 8;
     std::vector<uint8_t> line((size_t)w);
-    // unfilter in place
-    std::vector<uint8_t> prev(rowbytes, 0);
+    // unfilter the whole pass in place (tw_inflate.cpp: one loop per filter type, Paeth rows of 1-byte pixels two at a
+    // time), then convert row by row
+    if (!tw_png_unfilter(raw + pass_off, rowbytes, (size_t)h, fbpp)) return false;
     for (int y = 0; y < h; y++) {
         uint8_t* row = &raw[pass_off + (rowbytes + 1) * (size_t)y];
-        const int ft = row[0];
         uint8_t* cur = row + 1;
-        const uint8_t* pv = prev.data();
-        // one loop per filter type (the type is per row; a switch per byte made the unfilter, not the inflate, the
-        // cost of a decode); the first fbpp bytes have no left neighbour
-        const size_t head = std::min(fbpp, rowbytes);
-        switch (ft) {
-            case 0: break;
-            case 1:
-                for (size_t i = head; i < rowbytes; i++) cur[i] = (uint8_t)(cur[i] + cur[i - fbpp]);
-                break;
-            case 2:
-                for (size_t i = 0; i < rowbytes; i++) cur[i] = (uint8_t)(cur[i] + pv[i]);
-                break;
-            case 3:
-                for (size_t i = 0; i < head; i++) cur[i] = (uint8_t)(cur[i] + (pv[i] >> 1));
-                for (size_t i = head; i < rowbytes; i++) cur[i] = (uint8_t)(cur[i] + ((cur[i - fbpp] + pv[i]) >> 1));
-                break;
-            case 4:
-                for (size_t i = 0; i < head; i++) cur[i] = (uint8_t)(cur[i] + pv[i]);  // a = c = 0: the predictor is b
-                for (size_t i = head; i < rowbytes; i++) {
-                    const int a = cur[i - fbpp], b = pv[i], c = pv[i - fbpp];
-                    const int pa = abs(b - c), pb = abs(a - c), pc = abs(a + b - 2 * c);
-                    cur[i] = (uint8_t)(cur[i] + ((pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c)));
-                }
-                break;
-            default: return false;
-        }
-        memcpy(prev.data(), cur, rowbytes);
         uint8_t* out = line.data();
+        if (depth == 8 && ctype == 0 && dx == 1) {
+            memcpy(&img[(size_t)(y0 + y * dy) * W + x0], cur, (size_t)w);  // 8-bit gray, not interlaced: the row is the output
+            continue;
+        }
         auto sample8 = [&](size_t idx) -> int {  // idx-th sample of the row as 8 bits (16-bit: high byte)
             if (depth == 8) return cur[idx];
             if (depth == 16) return cur[idx * 2];
