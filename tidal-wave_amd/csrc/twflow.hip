@@ -1003,6 +1003,12 @@ void launch_blur(tw_engine* e, hipStream_t st, int w, int h, int ld, long long p
         // winSize 50/51 (BASELINE config 5): packed-f32 structure, single 58-row register window
 #ifdef TW_VARIANTS
         if (wide && e->blur_variant == 8) { hipLaunchKernelGGL((tw_blur_solve8<25, 256, 32, 8, true, false>), dim3((w + 191) / 192, gy, npairs), dim3(256), 0, st, a); return; }
+        // round 3 trials for config 5: shorter tiles make room for the R0 prefetch (QPRE)
+        if (wide && e->blur_variant == 256) { hipLaunchKernelGGL((tw_blur_solve4<25, 256, 32, 6, true, 2, 2, 2, true, false>), dim3((w + 191) / 192, (h + 5) / 6, npairs), dim3(256), 0, st, a); return; }
+        if (wide && e->blur_variant == 255) { hipLaunchKernelGGL((tw_blur_solve4<25, 256, 32, 5, true, 2, 2, 2, true, false>), dim3((w + 191) / 192, (h + 4) / 5, npairs), dim3(256), 0, st, a); return; }
+        if (wide && e->blur_variant == 254) { hipLaunchKernelGGL((tw_blur_solve4<25, 256, 32, 4, true, 2, 2, 2, true, false>), dim3((w + 191) / 192, (h + 3) / 4, npairs), dim3(256), 0, st, a); return; }
+        if (wide && e->blur_variant == 258) { hipLaunchKernelGGL((tw_blur_solve4<25, 256, 32, 8, true, 2, 2, 2, true, false>), dim3((w + 191) / 192, gy, npairs), dim3(256), 0, st, a); return; }
+        if (wide && e->blur_variant == 259) { hipLaunchKernelGGL((tw_blur_solve4<25, 256, 32, 5, true, 2, 2, 2, false, false>), dim3((w + 191) / 192, (h + 4) / 5, npairs), dim3(256), 0, st, a); return; }
 #endif
         if (wide) hipLaunchKernelGGL((tw_blur_solve4<25, 256, 32, 8, true, 2, 2, 2, false, false>), dim3((w + 191) / 192, gy, npairs), dim3(256), 0, st, a);
         else hipLaunchKernelGGL((tw_blur_solve8<25, 128, 32, 8, true, false>), dim3((w + 63) / 64, gy, npairs), dim3(128), 0, st, a);

@@ -56,6 +56,16 @@ tw_status tw_device_pci_bus_id(int device, char* buf, int cap)
     }
     return TW_OK;
 }
+tw_status tw_host_alloc(tw_engine*, size_t bytes, void** hptr)
+{
+    *hptr = malloc(bytes);
+    return *hptr ? TW_OK : TW_E_NOMEM;
+}
+tw_status tw_host_free(tw_engine*, void* hptr)
+{
+    free(hptr);
+    return TW_OK;
+}
 tw_status tw_prof_select(tw_engine*, int, int) { return TW_OK; }
 tw_status tw_prof_read(tw_engine*, int, double* ms, int* n)
 {

@@ -580,6 +580,52 @@ static void paeth_rows2_bpp1(uint8_t* r0, uint8_t* r1, const uint8_t* prev, size
     }
 }
 
+// K consecutive Paeth rows as a K-deep wavefront (row k runs k columns behind row 0): K independent serial chains per
+// iteration for the out-of-order core to overlap.  Rows are `pitch` bytes apart.
+template <int K>
+static void paeth_rowsK_bpp1(uint8_t* r0, size_t pitch, const uint8_t* prev, size_t n)
+{
+    int a[K], c[K];  // per row: left neighbour (its last output), upper-left
+    for (int k = 0; k < K; k++) a[k] = c[k] = 0;
+    auto step = [&](int k, size_t col) __attribute__((always_inline)) {
+        // the upper neighbour of row k at `col` is row k-1's output there = a[k-1] (row k-1 is exactly one column ahead and
+        // has not moved yet in this iteration: rows are stepped from the last to the first)
+        const int b = k == 0 ? prev[col] : a[k - 1];
+        const int d = b - c[k], t = a[k] - c[k];
+        const int pa = abs(d), pb = abs(t), pc = abs(t + d);
+        int pr = pb <= pc ? b : c[k];
+        pr = (pa <= pb && pa <= pc) ? a[k] : pr;
+        uint8_t* p = r0 + pitch * (size_t)k + col;
+        a[k] = (*p + pr) & 0xff;
+        *p = (uint8_t)a[k];
+        c[k] = b;
+    };
+    if (n < (size_t)K) {  // narrower than the wavefront is deep: row by row
+        for (int k = 0; k < K; k++)
+            for (size_t col = 0; col < n; col++) {
+                // (a[k-1] must be row k-1's output at `col`: re-read it)
+                const int b = k == 0 ? prev[col] : r0[pitch * (size_t)(k - 1) + col];
+                const int d = b - c[k], t = a[k] - c[k];
+                const int pa = abs(d), pb = abs(t), pc = abs(t + d);
+                int pr = pb <= pc ? b : c[k];
+                pr = (pa <= pb && pa <= pc) ? a[k] : pr;
+                uint8_t* p = r0 + pitch * (size_t)k + col;
+                a[k] = (*p + pr) & 0xff;
+                *p = (uint8_t)a[k];
+                c[k] = b;
+            }
+        return;
+    }
+    for (size_t i = 0; i < (size_t)K - 1; i++)  // ramp up: rows 0..i
+        for (int k = (int)i; k >= 0; k--) step(k, i - (size_t)k);
+    for (size_t i = K - 1; i < n; i++) {
+#pragma GCC unroll 8
+        for (int k = K - 1; k >= 0; k--) step(k, i - (size_t)k);
+    }
+    for (size_t i = n; i < n + K - 1; i++)  // drain: rows i-n+1 .. K-1
+        for (int k = K - 1; k > (int)(i - n); k--) step(k, i - (size_t)k);
+}
+
 bool tw_png_unfilter_row(int ft, uint8_t* cur, const uint8_t* pv, size_t rowbytes, size_t fbpp)
 {
     const size_t head = fbpp < rowbytes ? fbpp : rowbytes;
@@ -624,10 +670,19 @@ bool tw_png_unfilter(uint8_t* raw, size_t rowbytes, size_t rows, size_t fbpp)
     while (y < rows) {
         uint8_t* row = raw + pitch * y;
         const uint8_t* pv = y ? raw + pitch * (y - 1) + 1 : nullptr;
-        if (fbpp == 1 && pv && row[0] == 4 && y + 1 < rows && row[pitch] == 4) {
-            paeth_rows2_bpp1(row + 1, row + pitch + 1, pv, rowbytes);
-            y += 2;
-            continue;
+        if (fbpp == 1 && pv && row[0] == 4) {
+            size_t run = 1;
+            while (run < 4 && y + run < rows && row[pitch * run] == 4) run++;
+            if (run == 4) {  // (measured: 2 rows 3.9 ms, 4 rows 3.3 ms, 8 rows 3.8-4.8 ms per 1080p image)
+                paeth_rowsK_bpp1<4>(row + 1, pitch, pv, rowbytes);
+                y += 4;
+                continue;
+            }
+            if (run >= 2) {
+                paeth_rows2_bpp1(row + 1, row + pitch + 1, pv, rowbytes);
+                y += 2;
+                continue;
+            }
         }
         if (!tw_png_unfilter_row(row[0], row + 1, pv, rowbytes, fbpp)) return false;
         y++;

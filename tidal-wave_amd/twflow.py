@@ -66,9 +66,12 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        raise ImportError("libtwflow.so not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
-    _lib = _bind(LIB_PATH)
+    path = LIB_PATH
+    if os.environ.get("TWFLOW_VARIANTS") == "1":
+        path = VARIANTS_LIB_PATH  # tools/ A/B runs (kbench, sq_probe) of the kernels the product library leaves out
+    if not os.path.exists(path):
+        raise ImportError("%s not built: run `python -c 'import __graft_entry__ as g; g.build()'`" % os.path.basename(path))
+    _lib = _bind(path)
     return _lib
 
 

@@ -7,7 +7,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tidal-wave_amd"))
 import twflow as T  # noqa: E402
 
-W, H = 1920, 1080
+# KB_W / KB_H / KB_PARAMS="winSize=50,pyrLevels=5,pyrIterations=5" / KB_SLOTS select another configuration
+# (BASELINE config 5: KB_W=3840 KB_H=2160 with the parameters above)
+W, H = int(os.environ.get("KB_W", 1920)), int(os.environ.get("KB_H", 1080))
+PARAMS = {k: (float(v) if "." in v else int(v)) for k, v in
+          (kv.split("=") for kv in os.environ.get("KB_PARAMS", "").split(",") if kv)}
+SLOTS = int(os.environ.get("KB_SLOTS", 64))
 
 
 def main():
@@ -15,7 +20,7 @@ def main():
     only = int(sys.argv[2]) if len(sys.argv) > 2 else -1      # kernel class
     only_lv = int(sys.argv[3]) if len(sys.argv) > 3 else -1   # level
     only_flags = int(sys.argv[4]) if len(sys.argv) > 4 else -1
-    with T.Engine(0, T.default_params(), slots=64) as e:
+    with T.Engine(0, T.default_params(**PARAMS), slots=SLOTS) as e:
         L = e.num_levels(W, H)
         print("%-20s %5s %6s %10s %10s %8s" % ("kernel", "level", "pairs", "us/launch", "us/pair", "GB/s"))
         for kc in (T.K_PYR, T.K_POLYEXP, T.K_UPDATE_MATRICES, T.K_BLUR_SOLVE, T.K_SCAN):
@@ -34,7 +39,7 @@ def main():
                     b = e.algorithmic_bytes(kc, lv, W, H) * n
                     if kc == T.K_BLUR_SOLVE:
                         w, h = W >> lv, H >> lv
-                        b = (28 + (0 if flags & 2 else 68)) * w * h * n
+                        b = (28 + (0 if flags & 2 else 52)) * w * h * n  # as built: the refreshing launch moves 80 B/px
                     name = T.KERNEL_NAMES[kc] + ("(no refresh)" if flags & 2 else "")
                     print("%-20s %5d %6d %10.1f %10.2f %8.0f" % (name[:20], lv, n, us, us / n, b / us / 1e3 if b else 0))
 
