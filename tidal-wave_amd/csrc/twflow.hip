@@ -367,6 +367,7 @@ struct tw_engine {
     int pp_waves = 512;    // TW_PP_WAVES: below this many waves of 96x8 tiles a level takes the plane-parallel kernel
     unsigned long long* dbg_stamps = nullptr;  // TW_DEBUG_STAMPS=1: phase stamps of tw_pyr_taps (diagnostic runs only)
     int blur_nomask = 0;   // TW_BLUR_NOMASK
+    int blur_pipe = 0;     // TW_BLUR_PIPE: tiles a workgroup of tw_blur_solve4p walks (0: tw_blur_solve4 for every launch)
     int blur_small = -1;   // TW_BLUR_SMALL: force the small-grid tile choice of the 31-tap blur (-1: by grid size)
     int poly_variant = 1;  // 1: tw_polyexp_pk<N,8> (packed f32, default); 2: tw_polyexp_pk<N,16>; 0: tw_polyexp (scalar f32) — TW_POLY_VARIANT
     std::string err;
@@ -997,6 +998,21 @@ void launch_blur(tw_engine* e, hipStream_t st, int w, int h, int ld, long long p
         if (wide && e->blur_variant == 7) { hipLaunchKernelGGL((tw_blur_solve4<15, 256, 16, 8, true, 2, 2, 2, true, false>), dim3((w + a.xsh + 223) / 224, gy, npairs), dim3(256), 0, st, a); return; }
         if (wide && e->blur_variant == 6) { hipLaunchKernelGGL((tw_blur_solve4<15, 256, 16, 8, true, 2, 2, 2, false>), dim3((w + a.xsh + 223) / 224, gy, npairs), dim3(256), 0, st, a); return; }
 #endif
+#ifdef TW_VARIANTS
+        if (wide && update && e->blur_pipe > 0) {
+            // refreshing launch as a cross-tile pipeline: a workgroup walks blur_pipe vertically adjacent tiles
+            const int nt = e->blur_pipe;
+            const dim3 grid((w + a.xsh + 223) / 224, (gy + nt - 1) / nt, npairs);
+            switch (nt) {
+                case 3: hipLaunchKernelGGL((tw_blur_solve4p<15, 256, 16, 8, 3>), grid, dim3(256), 0, st, a); return;
+                case 5: hipLaunchKernelGGL((tw_blur_solve4p<15, 256, 16, 8, 5>), grid, dim3(256), 0, st, a); return;
+                case 9: hipLaunchKernelGGL((tw_blur_solve4p<15, 256, 16, 8, 9>), grid, dim3(256), 0, st, a); return;
+                case 15: hipLaunchKernelGGL((tw_blur_solve4p<15, 256, 16, 8, 15>), grid, dim3(256), 0, st, a); return;
+                case 109: hipLaunchKernelGGL((tw_blur_solve4p<15, 256, 16, 8, 9, 3>), dim3(grid.x, (gy + 8) / 9, npairs), dim3(256), 0, st, a); return;
+                default: break;
+            }
+        }
+#endif
         if (wide) hipLaunchKernelGGL((tw_blur_solve4<15, 256, 16, 8, true>), dim3((w + a.xsh + 223) / 224, gy, npairs), dim3(256), 0, st, a);
         else hipLaunchKernelGGL((tw_blur_solve4<15, 128, 16, 8, true>), dim3((w + a.xsh + 95) / 96, gy, npairs), dim3(128), 0, st, a);
     } else if (e->win_m == 25) {
@@ -1578,14 +1594,15 @@ tw_status tw_engine_create(int device, const tw_params* params, int slots, tw_en
     if (const char* ev = getenv("TW_BLUR_SMALL")) e->blur_small = atoi(ev);
     if (const char* ev = getenv("TW_PP_WAVES")) e->pp_waves = atoi(ev);
     if (const char* ev = getenv("TW_BLUR_NOMASK")) e->blur_nomask = atoi(ev);
+    if (const char* ev = getenv("TW_BLUR_PIPE")) e->blur_pipe = atoi(ev);
 #ifndef TW_VARIANTS
     // The measured-slower A/B kernels are compiled only into `make VARIANTS=1` builds (libtwflow_variants.so): a
     // default build refuses their switches instead of silently running something else.
     {
-        const bool bad = (e->blur_variant != 4) || (e->poly_variant != 1) || (e->blur_small == 2 || e->blur_small == 3 ||
+        const bool bad = (e->blur_variant != 4) || (e->poly_variant != 1) || (e->blur_pipe != 0) || (e->blur_small == 2 || e->blur_small == 3 ||
                          e->blur_small == 5) || (getenv("TW_UPD_NY") && atoi(getenv("TW_UPD_NY")) == 1);
         if (bad) {
-            fprintf(stderr, "twflow: TW_BLUR_VARIANT / TW_POLY_VARIANT / TW_BLUR_SMALL=2,3,5 / TW_UPD_NY=1 select kernels "
+            fprintf(stderr, "twflow: TW_BLUR_VARIANT / TW_POLY_VARIANT / TW_BLUR_PIPE / TW_BLUR_SMALL=2,3,5 / TW_UPD_NY=1 select kernels "
                             "that are only in a VARIANTS=1 build (tidal-wave_amd/libtwflow_variants.so)\n");
             delete e;
             return TW_E_UNSUPPORTED;

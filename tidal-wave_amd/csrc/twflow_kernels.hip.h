@@ -32,6 +32,15 @@ __device__ __forceinline__ float gload(gptr_cf row, unsigned byte_off)
 {
     return *(gptr_cf)((gptr_cc)row + byte_off);
 }
+typedef float __attribute__((address_space(1))) * gptr_f;
+typedef char __attribute__((address_space(1))) * gptr_c;
+__device__ __forceinline__ gptr_f sgpr_base_w(float* p)
+{
+    gptr_f g = (gptr_f)p;
+    asm volatile("" : "+s"(g));
+    return g;
+}
+__device__ __forceinline__ void gstore(gptr_f row, unsigned byte_off, float v) { *(gptr_f)((gptr_c)row + byte_off) = v; }
 
 // Raw buffer access: one resource descriptor (4 SGPRs) per image set, a wave-uniform 32-bit byte offset in
 // an SGPR (row / plane) and the lane's column as a 32-bit VGPR byte offset.  No per-load VALU address math
@@ -1154,6 +1163,29 @@ __device__ __forceinline__ void update_matrices_gather(const float* __restrict__
         T.t[c][3] = p[c * ps + ld + 1];
     }
 }
+// The same gather with wave-uniform plane bases in SGPR pairs and ONE 32-bit byte offset per lane and pixel (planes are
+// below 4 GiB: check_dims): 20 loads share two offset registers instead of carrying a 64-bit address each — what lets
+// tw_blur_solve4p keep two pixels of taps in flight beside a 38-row register window.
+__device__ __forceinline__ void update_matrices_gather_s(const float* __restrict__ R1, long long ps, int ld, int w, int h,
+                                                         int x, int y, float dx, float dy, UpdTaps& T)
+{
+    float fx = (float)x + dx, fy = (float)y + dy;
+    const float flx = floorf(fx), fly = floorf(fy);
+    const bool inb = flx >= 0.f && flx < (float)(w - 1) && fly >= 0.f && fly < (float)(h - 1);
+    const int x1 = inb ? (int)flx : 0, y1 = inb ? (int)fly : 0;
+    T.fx = fx - (float)x1;
+    T.fy = fy - (float)y1;
+    T.inb = inb;
+    const unsigned o0 = (unsigned)(y1 * ld + x1) * 4u, o1 = o0 + (unsigned)ld * 4u;
+#pragma unroll
+    for (int c = 0; c < 5; c++) {
+        const gptr_cf b = sgpr_base(R1 + c * ps);
+        T.t[c][0] = gload(b, o0);
+        T.t[c][1] = gload(b, o0 + 4u);
+        T.t[c][2] = gload(b, o1);
+        T.t[c][3] = gload(b, o1 + 4u);
+    }
+}
 // ... and its arithmetic
 __device__ __forceinline__ void update_matrices_combine(const float q[5], const UpdTaps& T, int w, int h, int x, int y,
                                                         float dx, float dy, float M[5])
@@ -1595,6 +1627,255 @@ __global__ __launch_bounds__(COLS) __attribute__((amdgpu_waves_per_eu(4, 8))) vo
         }
     }
 }
+
+#ifdef TW_VARIANTS  // round-3 trial (TW_BLUR_PIPE), measured 55 % slower: VARIANTS=1 builds only (profiles/r03_blur_pipeline_negative.md)
+// -----------------------------------------------------------------------------------------------------
+// tw_blur_solve4p<MH,COLS,HALO,TH,NT> : tw_blur_solve4's refreshing launch as a CROSS-TILE PIPELINE.
+//   A workgroup walks NT vertically adjacent tiles.  The FarnebackUpdateMatrices refresh of tile t-1 — R0 loads, the
+//   flow-dependent R1 gathers, the combine, the M stores: traffic that tw_blur_solve4 leaves exposed at the end of every
+//   tile — is interleaved with the VERTICAL pass of tile t, one round of two pixels per M plane:
+//       per plane ch:  V arithmetic(ch) | issue window loads(ch+1) | combine + store round ch-1 | issue gathers round ch
+//   so the gathers fly under ~370 VALU instructions of window arithmetic and the window loads under the combine.
+//   What makes it fit the 128-VGPR budget of four waves per SIMD: one register window (no next-plane double buffer), two
+//   pixels of taps in flight, R0 fetched with the gathers (no 35-register prefetch), and the flows of the previous
+//   tile's seven pixels carried in 14 registers.  Same values, same order per value as tw_blur_solve4; used for
+//   refreshing launches only (the last iteration of a level has no refresh to hide).
+// -----------------------------------------------------------------------------------------------------
+template <int MH, int COLS, int HALO, int TH, int NT, int WPE = 4>
+__global__ __launch_bounds__(COLS) __attribute__((amdgpu_waves_per_eu(WPE, 8))) void tw_blur_solve4p(BlurArgs a)
+{
+    constexpr int TW = COLS - 2 * HALO;
+    constexpr int NW = TH + 2 * MH;
+    __shared__ __attribute__((aligned(16))) float sm[5][TH][COLS];
+    const int tid = threadIdx.x;
+    int bx, by, z;
+    xcd_remap(bx, by, z);
+    const int x0 = bx * TW - a.xsh;
+    const WinCoef& c = a.c;
+    const float* __restrict__ Min = a.Min + (long long)z * 5 * a.ps;
+    float* __restrict__ flow = a.flow + (long long)z * 2 * a.fps;
+    float* __restrict__ Mout = a.Mout + (long long)z * 5 * a.ps;
+    const float* __restrict__ R0 = a.R + (long long)(2 * z) * 5 * a.ps;
+    const float* __restrict__ R1 = R0 + 5 * a.ps;
+    // partial tiles (the last tile column): as in tw_blur_solve4 — the same for every tile of the column
+    const int cx0 = max(0, -x0), vw = min(TW, a.w - x0) - cx0;
+    const bool partial = !a.nomask && vw <= TW - 32;
+    const int gq0 = cx0 >> 2, gv = ((cx0 + vw + 3) >> 2) - gq0;
+    const float inv_gv = 1.f / (float)gv, inv_vw = 1.f / (float)vw;
+    constexpr int GROUPS = TW / 4;
+    constexpr int NITEM = TH * GROUPS;
+    constexpr int ROUNDS = (NITEM + COLS - 1) / COLS;
+    constexpr int WL = 4 + 2 * HALO;
+    constexpr int NPX = (TH * TW + COLS - 1) / COLS;
+    constexpr bool RAGGED = (TH * TW) % COLS != 0;
+    constexpr int NRND = (NPX + 1) / 2;  // refresh rounds of two pixels
+    static_assert(NRND <= 4, "a refresh round per M plane: issue at planes 0..3, combine at planes 1..4");
+    // S-phase pixel i of this lane within a tile: row r, column cx; false when the tile has no such pixel for any lane
+    // of the wave (wave-uniform: partial tiles take fewer rounds)
+    // (`lane` is the thread index, handed in as an opaque copy by every phase: otherwise the coordinates and 64-bit
+    // offsets of all seven pixels are hoisted out of the tile loop and live in ~40 registers for the whole kernel)
+    auto pixel = [&](int lane, int i, bool& mine, int& r, int& cx) -> bool {
+        if (partial) {
+            if (i * COLS >= TH * vw) return false;
+            mine = lane + i * COLS < TH * vw;
+            const int p = mine ? lane + i * COLS : TH * vw - 1;
+            r = (int)(((float)p + 0.5f) * inv_vw);
+            cx = cx0 + p - r * vw;
+        } else {
+            mine = !RAGGED || lane + i * COLS < TH * TW;
+            const int p = mine ? lane + i * COLS : TH * TW - 1;
+            r = p / TW;
+            const int c0 = p - r * TW + a.rot;
+            cx = c0 >= TW ? c0 - TW : c0;
+        }
+        return true;
+    };
+    const bool vact = a.nomask || (x0 - HALO + tid >= -MH && x0 - HALO + tid <= a.w - 1 + MH);
+    const unsigned xb = (unsigned)clampi(x0 - HALO + tid, 0, a.w - 1) * 4u;
+
+    float pfx[NPX], pfy[NPX];  // flows of the previous tile's pixels (the refresh that is still owed)
+    bool have_prev = false;
+    int py0 = 0;
+#pragma unroll 1
+    for (int t = 0; t <= NT; t++) {
+        const int y0 = (by * NT + t) * TH;
+        const bool have = t < NT && y0 < a.h;  // workgroup-uniform
+        if (!have && !have_prev) break;
+        const bool vrun = have && vact;
+
+        // ---- V(t) interleaved with the refresh of tile t-1 ----
+        UpdTaps T[2];
+        float q[2][5];
+        auto issue_round = [&](int g) __attribute__((always_inline)) {
+            int lane = tid;
+            asm volatile("" : "+v"(lane));
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const int i = 2 * g + j;
+                if (i >= NPX) break;
+                bool mine;
+                int r, cx;
+                if (!pixel(lane, i, mine, r, cx)) break;
+                const int xc = clampi(x0 + cx, 0, a.w - 1), yc = min(py0 + r, a.h - 1);
+                const unsigned o = (unsigned)(yc * a.ld + xc) * 4u;
+#pragma unroll
+                for (int cc = 0; cc < 5; cc++) q[j][cc] = gload(sgpr_base(R0 + cc * a.ps), o);
+                update_matrices_gather_s(R1, a.ps, a.ld, a.w, a.h, xc, yc, pfx[i], pfy[i], T[j]);
+            }
+        };
+        auto finish_round = [&](int g) __attribute__((always_inline)) {
+            int lane = tid;
+            asm volatile("" : "+v"(lane));
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const int i = 2 * g + j;
+                if (i >= NPX) break;
+                bool mine;
+                int r, cx;
+                if (!pixel(lane, i, mine, r, cx)) break;
+                const int x = x0 + cx, y = py0 + r;
+                const bool valid = mine && x >= 0 && x < a.w && y < a.h;
+                const int xc = clampi(x, 0, a.w - 1), yc = min(y, a.h - 1);
+                float M[5];
+                update_matrices_combine(q[j], T[j], a.w, a.h, xc, yc, pfx[i], pfy[i], M);
+                if (valid) {
+                    const unsigned o = (unsigned)(yc * a.ld + xc) * 4u;
+#pragma unroll
+                    for (int cc = 0; cc < 5; cc++) gstore(sgpr_base_w(Mout + cc * a.ps), o, M[cc]);
+                }
+            }
+        };
+        {
+            float wa[NW];
+            const unsigned pitch = (unsigned)a.ld * 4u;
+            // the NW clamped row offsets are recomputed per plane on the scalar unit (an opaque zero keeps them from
+            // being hoisted into 38 SGPRs for the whole tile: with the refresh's pointers beside them they would spill)
+            auto load_window = [&](int ch) __attribute__((always_inline)) {
+                const __amdgpu_buffer_rsrc_t rs = make_rsrc(Min + (long long)ch * a.ps);
+                int zero;
+                asm volatile("s_mov_b32 %0, 0" : "=s"(zero));
+#pragma unroll
+                for (int i = 0; i < NW; i++)
+                    wa[i] = bload(rs, xb, (unsigned)clampi(y0 - MH + i + zero, 0, a.h - 1) * pitch);
+            };
+            if (vrun) load_window(0);
+            if (have_prev) issue_round(0);
+#pragma unroll
+            for (int ch = 0; ch < 5; ch++) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (vrun) {
+#pragma unroll
+                    for (int r = 0; r < TH; r++) {
+                        float s0 = wa[r + MH] * c.k[0];
+#pragma unroll
+                        for (int i = 1; i <= MH; i++) s0 += (wa[r + MH + i] + wa[r + MH - i]) * c.k[i];
+                        sm[ch][r][tid] = s0;
+                        if (r & 1) __builtin_amdgcn_sched_barrier(0);  // two rows in flight
+                    }
+                    if (ch < 4) load_window(ch + 1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (have_prev) {
+                    if (ch < NRND) finish_round(ch);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (ch + 1 < NRND) issue_round(ch + 1);
+                }
+            }
+        }
+        if (!have) break;  // the drain step: nothing but the last tile's refresh
+        __syncthreads();
+
+        // ---- H: all planes, results in registers (as tw_blur_solve4) ----
+        f32x4 res[ROUNDS][5];
+#pragma unroll
+        for (int rd = 0; rd < ROUNDS; rd++) {
+            const int it = tid + rd * COLS;
+            int r, qd;
+            bool on;
+            if (partial) {
+                on = it < TH * gv;
+                r = (int)(((float)it + 0.5f) * inv_gv);
+                qd = gq0 + it - r * gv;
+            } else {
+                r = it / GROUPS;
+                qd = it - r * GROUPS;
+                on = it < NITEM && (a.nomask || (x0 + 4 * qd < a.w && x0 + 4 * qd + 3 >= 0));
+            }
+            if (on) {
+#pragma unroll
+                for (int ch = 0; ch < 5; ch++) {
+                    float v[WL];
+#pragma unroll
+                    for (int u = 0; u < WL / 4; u++) {
+                        const f32x4 A = *(const f32x4*)&sm[ch][r][4 * qd + 4 * u];
+                        v[4 * u] = A[0];
+                        v[4 * u + 1] = A[1];
+                        v[4 * u + 2] = A[2];
+                        v[4 * u + 3] = A[3];
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const int li = HALO + j;
+                        float sum = v[li] * c.k[0];
+#pragma unroll
+                        for (int i = 1; i <= MH; i++) sum += c.k[i] * (v[li - i] + v[li + i]);
+                        res[rd][ch][j] = sum;
+                        if (j & 1) __builtin_amdgcn_sched_barrier(0);  // two pixels in flight
+                    }
+                }
+            }
+        }
+        __syncthreads();  // every window has been read: the interiors may be overwritten
+#pragma unroll
+        for (int rd = 0; rd < ROUNDS; rd++) {
+            const int it = tid + rd * COLS;
+            int r, qd;
+            bool on;
+            if (partial) {
+                on = it < TH * gv;
+                r = (int)(((float)it + 0.5f) * inv_gv);
+                qd = gq0 + it - r * gv;
+            } else {
+                r = it / GROUPS;
+                qd = it - r * GROUPS;
+                on = it < NITEM && (a.nomask || (x0 + 4 * qd < a.w && x0 + 4 * qd + 3 >= 0));
+            }
+            if (on) {
+#pragma unroll
+                for (int ch = 0; ch < 5; ch++) *(f32x4*)&sm[ch][r][HALO + 4 * qd] = res[rd][ch];
+            }
+        }
+        __syncthreads();
+
+        // ---- solve: the flows of this tile's pixels stay in registers; their refresh rides on the next tile's V ----
+        int slane = tid;
+        asm volatile("" : "+v"(slane));
+#pragma unroll
+        for (int i = 0; i < NPX; i++) {
+            bool mine;
+            int r, cx;
+            if (!pixel(slane, i, mine, r, cx)) break;
+            const double g11 = sm[0][r][HALO + cx], g12 = sm[1][r][HALO + cx], g22 = sm[2][r][HALO + cx],
+                         h1 = sm[3][r][HALO + cx], h2 = sm[4][r][HALO + cx];
+            const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
+            pfx[i] = (float)((g11 * h2 - g12 * h1) * idet);
+            pfy[i] = (float)((g22 * h1 - g12 * h2) * idet);
+            if (a.store_flow) {
+                const int x = x0 + cx, y = y0 + r;
+                if (mine && x >= 0 && x < a.w && y < a.h) {
+                    const long long o = (long long)y * a.ld + x;
+                    flow[o] = pfx[i];
+                    flow[o + a.fps] = pfy[i];
+                }
+            }
+        }
+        have_prev = true;
+        py0 = y0;
+        __syncthreads();  // the next tile's V overwrites the LDS tile
+    }
+}
+
+#endif  // TW_VARIANTS (tw_blur_solve4p)
 
 #ifdef TW_VARIANTS  // A/B kernel (TW_BLUR_VARIANT=60/61, measured 18-68 % slower): VARIANTS=1 builds only
 // -----------------------------------------------------------------------------------------------------

@@ -37,10 +37,11 @@ def main():
     th.start()
     runs = []
     with T.Engine(0, T.default_params(), slots=64) as e:
-        for name, kc, lv, flags in (("tw_pyr_k3<0> (level 0)", T.K_PYR, 0, 0), ("tw_pyr_taps<19> (level 3)", T.K_PYR, 3, 0),
+        only = os.environ.get("PPK_ONLY", "")  # e.g. PPK_ONLY=fused: just the rows whose name contains it
+        for name, kc, lv, flags in (r for r in (("tw_pyr_k3<0> (level 0)", T.K_PYR, 0, 0), ("tw_pyr_taps<19> (level 3)", T.K_PYR, 3, 0),
                                     ("tw_polyexp_pk<7,8>", T.K_POLYEXP, 0, 0), ("tw_update_matrices<true,2>", T.K_UPDATE_MATRICES, 0, 0),
                                     ("tw_blur_solve4 fused with the refresh", T.K_BLUR_SOLVE, 0, 0),
-                                    ("tw_blur_solve4 last iteration", T.K_BLUR_SOLVE, 0, 2)):
+                                    ("tw_blur_solve4 last iteration", T.K_BLUR_SOLVE, 0, 2)) if only in r[0]):
             us = e.bench_stage(kc, W, H, lv, 64, 3, flags)
             iters = max(10, int(2.0e6 / us))
             t0 = time.time()
