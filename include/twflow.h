@@ -137,7 +137,8 @@ tw_status tw_dev_upload(tw_engine* e, void* dptr, const void* host, size_t bytes
  * TW_OPT_POLYEXP_F32 (default 0): MEASUREMENT variant of the polynomial expansion with float instead of double
  *   horizontal accumulators (polyN 5 or 7; what OpenCV's CUDA module does).  NOT bit-identical to the CPU reference;
  *   exists so that "what would the kernel cost without its f64 half, and what would it do to the flow" is a number
- *   (bench.py `polyexp_f32_variant`, profiles/r03_polyexp_f32.md).  Never on by default, never bench.py's `value`. */
+ *   (bench.py `polyexp_f32_variant`, profiles/r03_polyexp_f32.md).  Value 2 (polyN 7) additionally fuses every
+ *   multiply-add (v_pk_fma_f32).  Never on by default, never bench.py's `value`. */
 enum { TW_OPT_SCAN_FUSED_FINAL = 1, TW_OPT_POLYEXP_F32 = 2 };
 tw_status tw_set_option(tw_engine* e, int option, int value);
 

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_committed_bench_line_has_the_contract_keys():
-    d = json.load(open(os.path.join(ROOT, "profiles", "r02_bench.json")))
+    d = json.load(open(os.path.join(ROOT, "profiles", "r03_bench.json")))
     base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
     assert d["metric"] == base["metric"] and d["unit"] == "pairs/s" and d["higher_is_better"] is True
     for k in ("value", "n_gpus", "steps", "warmup", "ms_per_step", "scaling", "vs_baseline", "dtype", "data", "config"):
@@ -35,6 +35,18 @@ def test_committed_bench_line_has_the_contract_keys():
     # the other BASELINE configs ride in the same line
     assert d["config3_host_pinned"]["pairs_per_s"] > 0 and d["config5_4k"]["pairs_per_s"] > 0
     assert d["queue_sharded"]["pairs_per_s"] > 0 and d["queue_sharded"]["errors"] == 0
+    assert d["queue_sharded"]["all_consumers_warm"] is True
+    # round 3: the workload is named, config 3 reports fill and steady state, config 5 has its own kernel roofline, the
+    # service-from-files figure and the polyexp measurement variant ride in the line
+    assert d["config"]["mode"] == "resident" and d["config"]["workload"].startswith("resident:")
+    c3 = d["config3_host_pinned"]
+    assert c3["pairs"] >= 2048 and c3["engine_batch"] == 128 and c3["steady_state_pairs_per_s"] > c3["pairs_per_s"] > 0
+    c5 = d["config5_4k"]
+    assert c5["pairs"] >= 64 and c5["distinct_pairs"] >= 4 and 0.1 < c5["roofline_cfg5"]["frac"] < 1.0
+    assert d["files_e2e"]["pairs_per_s"] >= 800 and d["files_e2e"]["errors"] == 0
+    pv = d["polyexp_f32_variant"]
+    assert 0.3 < pv["frac"] < 0.6 and pv["max_abs_flow_err"] > 1e-3 and pv["vectors_identical"] is False
+    assert d["config"]["single_pair_latency_ms"] < 0.45
     # value is consistent with the step time and the batch
     assert abs(d["value"] - d["config"]["batch_per_gpu"] * d["n_gpus"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 0.01
 

@@ -477,6 +477,69 @@ def test_box_window_and_flag_bits(twflow, oracle, kw):
     assert v2 == oracle.span_scan(ux, uy, 10, 1.0)
 
 
+def test_polyexp_f32_measurement_option_is_off_by_default_and_does_not_leak(twflow, oracle):
+    """TW_OPT_POLYEXP_F32 is a measurement variant: with it the flow is close to, but NOT, the oracle's
+    (float / fused accumulation instead of the CPU's double); switched off again the engine is bit-exact as before."""
+    import synth
+    a, b = synth.make_pair(0, 270, 480)
+    wx, wy = oracle.farneback(a, b)
+    with twflow.Engine(0, twflow.default_params(), slots=1) as e:
+        gx, gy, _ = e.calculate_internal(a, b)
+        assert_same(gx, wx, "default flowx")
+        for opt in (1, 2):
+            e.set_option(twflow.OPT_POLYEXP_F32, opt)
+            fx, fy, _ = e.calculate_internal(a, b)
+            assert not np.array_equal(fx, wx)
+            assert np.abs(fx - wx).max() < 0.5 and np.abs(fy - wy).max() < 0.5
+        e.set_option(twflow.OPT_POLYEXP_F32, 0)
+        gx, gy, _ = e.calculate_internal(a, b)
+        assert_same(gx, wx, "flowx after the option was switched off")
+        assert_same(gy, wy, "flowy after the option was switched off")
+    with twflow.Engine(0, twflow.default_params(polyN=3), slots=1) as e:
+        e.set_option(twflow.OPT_POLYEXP_F32, 1)
+        with pytest.raises(twflow.TwError):
+            e.calculate_internal(a, b)   # polyN 5 / 7 only
+
+
+def test_page_lock_table_is_process_wide_and_never_stale(twflow, oracle):
+    """"is this pointer page-locked?" used to be a per-engine cache of runtime answers, which went stale
+    when another engine freed the block (bench_queue does) — a stale yes turns the safe staged upload into a DMA from
+    pageable memory.  Now the library keeps one process-wide table of the blocks it handed out / was told about:
+    a block one engine allocated is DMA-ed from by another; once it is freed (by either) its address is pageable again;
+    caller memory can be registered and unregistered; freeing what the table does not know is an error."""
+    import ctypes as C
+    rng = np.random.default_rng(77)
+    a = rand_img(rng, 120, 200)
+    b = np.roll(a, 3, axis=1)
+    wx, wy = oracle.farneback(a, b)
+    want = oracle.span_scan(wx, wy, 10, 1.0)
+    L = twflow.lib()
+    with twflow.Engine(0, twflow.default_params(), slots=2) as e1, twflow.Engine(0, twflow.default_params(), slots=2) as e2:
+        pa, pb = e1.host_array(a.shape), e1.host_array(b.shape)   # allocated through engine 1 ...
+        pa[:] = a
+        pb[:] = b
+        assert e2.wait(e2.submit(pa, pb, 10, 1.0))["vector"] == want    # ... uploaded from by engine 2
+        # engine 2 frees engine 1's blocks (tw_host_free is allowed from any engine); the arrays are gone after this
+        addr_a, addr_b = pa.ctypes.data, pb.ctypes.data
+        del pa, pb
+        for h in list(e1._hostbufs):
+            assert L.tw_host_free(e2._h, h) == twflow.TW_OK
+        e1._hostbufs = []
+        assert L.tw_host_free(e2._h, C.c_void_p(addr_a)) == twflow.TW_E_BAD_PARAMETER   # not in the table any more
+        # caller-owned memory: registered -> direct DMA, unregistered -> staged; both give the oracle's vectors
+        buf = np.empty((2,) + a.shape, np.uint8)
+        buf[0], buf[1] = a, b
+        assert L.tw_host_register(e1._h, C.c_void_p(buf.ctypes.data), buf.nbytes) == twflow.TW_OK
+        assert e1.wait(e1.submit(buf[0], buf[1], 10, 1.0))["vector"] == want
+        assert e2.wait(e2.submit(buf[0], buf[1], 10, 1.0))["vector"] == want
+        assert L.tw_host_unregister(e2._h, C.c_void_p(buf.ctypes.data)) == twflow.TW_OK
+        assert L.tw_host_unregister(e2._h, C.c_void_p(buf.ctypes.data)) == twflow.TW_E_BAD_PARAMETER
+        buf[0, 5:9, 5:9] = 0  # pageable now: may change right after submit returns (staged)
+        t = e1.submit(buf[0], buf[1], 10, 1.0)
+        ux, uy = oracle.farneback(buf[0], buf[1])
+        assert e1.wait(t)["vector"] == oracle.span_scan(ux, uy, 10, 1.0)
+
+
 def test_strided_input_and_errors(engine, twflow, oracle):
     rng = np.random.default_rng(5)
     big = rand_img(rng, 100, 300)

@@ -369,6 +369,7 @@ struct tw_engine {
     int blur_nomask = 0;   // TW_BLUR_NOMASK
     int blur_pipe = 0;     // TW_BLUR_PIPE: tiles a workgroup of tw_blur_solve4p walks (0: tw_blur_solve4 for every launch)
     int blur_small = -1;   // TW_BLUR_SMALL: force the small-grid tile choice of the 31-tap blur (-1: by grid size)
+    int blur_small_lv[8] = {-1, -1, -1, -1, -1, -1, -1, -1};  // TW_BLUR_SMALL_LEVELS="a,b,c,d": the same per pyramid level
     int poly_variant = 1;  // 1: tw_polyexp_pk<N,8> (packed f32, default); 2: tw_polyexp_pk<N,16>; 0: tw_polyexp (scalar f32) — TW_POLY_VARIANT
     std::string err;
     // device workspace, shared by all batches (execution is ordered on one stream)
@@ -844,8 +845,11 @@ tw_status launch_polyexp(tw_engine* e, hipStream_t st, int w, int h, int ld, lon
     if (e->poly_f32) {
         // measurement variant (TW_OPT_POLYEXP_F32): float horizontal accumulators — NOT bit-exact, never the default
         switch (e->p.polyN) {
-            case 5: hipLaunchKernelGGL((tw_polyexp_pk<5, 8, true>), grid, dim3(256), 0, st, a); break;
-            case 7: hipLaunchKernelGGL((tw_polyexp_pk<7, 8, true>), grid, dim3(256), 0, st, a); break;
+            case 5: hipLaunchKernelGGL((tw_polyexp_pk<5, 8, 1>), grid, dim3(256), 0, st, a); break;
+            case 7:
+                if (e->poly_f32 == 2) hipLaunchKernelGGL((tw_polyexp_pk<7, 8, 2>), grid, dim3(256), 0, st, a);
+                else hipLaunchKernelGGL((tw_polyexp_pk<7, 8, 1>), grid, dim3(256), 0, st, a);
+                break;
             default: e->err = "TW_OPT_POLYEXP_F32 needs polyN 5 or 7"; return TW_E_UNSUPPORTED;
         }
         return TW_OK;
@@ -857,12 +861,12 @@ tw_status launch_polyexp(tw_engine* e, hipStream_t st, int w, int h, int ld, lon
     if (t16) grid.y = (h + 15) / 16;
 #define TW_PK_CASE(n)                                                                        \
     case n:                                                                                  \
-        if (t16) hipLaunchKernelGGL((tw_polyexp_pk<n, 16>), grid, dim3(256), 0, st, a);      \
-        else hipLaunchKernelGGL((tw_polyexp_pk<n, 8>), grid, dim3(256), 0, st, a);           \
+        if (t16) hipLaunchKernelGGL((tw_polyexp_pk<n, 16, 0>), grid, dim3(256), 0, st, a);      \
+        else hipLaunchKernelGGL((tw_polyexp_pk<n, 8, 0>), grid, dim3(256), 0, st, a);           \
         break;
 #else
 #define TW_PK_CASE(n)                                                                        \
-    case n: hipLaunchKernelGGL((tw_polyexp_pk<n, 8>), grid, dim3(256), 0, st, a); break;
+    case n: hipLaunchKernelGGL((tw_polyexp_pk<n, 8, 0>), grid, dim3(256), 0, st, a); break;
 #endif
     switch (e->p.polyN) {
         TW_PK_CASE(1) TW_PK_CASE(2) TW_PK_CASE(3) TW_PK_CASE(4) TW_PK_CASE(5) TW_PK_CASE(6) TW_PK_CASE(7)
@@ -951,7 +955,8 @@ void launch_blur(tw_engine* e, hipStream_t st, int w, int h, int ld, long long p
         auto nwg = [&](int tw, int th) { return (long long)((w + tw - 1) / tw) * ((h + th - 1) / th) * npairs; };
         int small = 0;  // 0: 224x8 / 96x8 tiles as below, 1: 96x8 (128 threads), 2: 96x4 (128 threads), 3: 32x4 (64 threads)
                         // 4: plane-parallel 32x8 (320 threads), 5: plane-parallel 96x8 (640 threads)
-        if (e->blur_small >= 0) small = e->blur_small;
+        if (level >= 0 && level < 8 && e->blur_small_lv[level] >= 0) small = e->blur_small_lv[level];
+        else if (e->blur_small >= 0) small = e->blur_small;
         else if (wide && nwg(224, 8) >= 1024) small = 0;   // four 256-thread workgroups per CU: throughput regime
         else if (nwg(96, 8) * 2 >= e->pp_waves) small = wide ? 1 : 0;  // enough 2-wave workgroups to keep every SIMD busy
         else small = 4;  // otherwise many small plane-parallel workgroups (5 waves per 32x8 pixels)
@@ -1592,14 +1597,25 @@ tw_status tw_engine_create(int device, const tw_params* params, int slots, tw_en
     if (const char* ev = getenv("TW_PYR_GENERIC")) e->pyr_generic = atoi(ev);
     if (const char* ev = getenv("TW_POLY_VARIANT")) e->poly_variant = atoi(ev);
     if (const char* ev = getenv("TW_BLUR_SMALL")) e->blur_small = atoi(ev);
+    if (const char* ev = getenv("TW_BLUR_SMALL_LEVELS")) {
+        int k = 0;
+        for (const char* q = ev; *q && k < 8; k++) {
+            e->blur_small_lv[k] = atoi(q);
+            while (*q && *q != ',') q++;
+            if (*q == ',') q++;
+        }
+    }
     if (const char* ev = getenv("TW_PP_WAVES")) e->pp_waves = atoi(ev);
     if (const char* ev = getenv("TW_BLUR_NOMASK")) e->blur_nomask = atoi(ev);
     if (const char* ev = getenv("TW_BLUR_PIPE")) e->blur_pipe = atoi(ev);
+    if (const char* ev = getenv("TW_POLYEXP_F32")) e->poly_f32 = atoi(ev) == 2 ? 2 : (atoi(ev) ? 1 : 0);  // = TW_OPT_POLYEXP_F32 (measurement runs)
 #ifndef TW_VARIANTS
     // The measured-slower A/B kernels are compiled only into `make VARIANTS=1` builds (libtwflow_variants.so): a
     // default build refuses their switches instead of silently running something else.
     {
-        const bool bad = (e->blur_variant != 4) || (e->poly_variant != 1) || (e->blur_pipe != 0) || (e->blur_small == 2 || e->blur_small == 3 ||
+        bool bad_lv = false;
+        for (int v : e->blur_small_lv) bad_lv = bad_lv || v == 2 || v == 3 || v == 5;
+        const bool bad = bad_lv || (e->blur_variant != 4) || (e->poly_variant != 1) || (e->blur_pipe != 0) || (e->blur_small == 2 || e->blur_small == 3 ||
                          e->blur_small == 5) || (getenv("TW_UPD_NY") && atoi(getenv("TW_UPD_NY")) == 1);
         if (bad) {
             fprintf(stderr, "twflow: TW_BLUR_VARIANT / TW_POLY_VARIANT / TW_BLUR_PIPE / TW_BLUR_SMALL=2,3,5 / TW_UPD_NY=1 select kernels "
@@ -1844,7 +1860,7 @@ tw_status tw_set_option(tw_engine* e, int option, int value)
     if (!e) return TW_E_BAD_PARAMETER;
     switch (option) {
         case TW_OPT_SCAN_FUSED_FINAL: e->scan_fused = value ? 1 : 0; return TW_OK;
-        case TW_OPT_POLYEXP_F32: e->poly_f32 = value ? 1 : 0; return TW_OK;
+        case TW_OPT_POLYEXP_F32: e->poly_f32 = value == 2 ? 2 : (value ? 1 : 0); return TW_OK;
         default: e->err = "unknown option"; return TW_E_BAD_PARAMETER;
     }
 }

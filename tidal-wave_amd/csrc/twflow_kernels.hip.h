@@ -880,9 +880,18 @@ __global__ __launch_bounds__(256) void tw_polyexp(PolyArgs a)
 // F32ACC = true is a MEASUREMENT variant only (engine option TW_OPT_POLYEXP_F32, never the default): the horizontal
 // accumulators b1..b6 are float instead of the CPU code's double — what OpenCV's own CUDA kernel does.  Not bit-exact;
 // exists to put a number on "what would polyexp cost without the f64 half" (profiles/r03_polyexp_f32.md).
-template <int N, int TH, bool F32ACC = false>
+// F32ACC = 2 additionally FUSES every multiply-add of both passes (v_pk_fma_f32: what a CUDA build of OpenCV's own GPU
+// kernel does by default) — the cheapest arithmetic the algorithm admits, even further from the CPU's bits.
+template <bool FUSE>
+__device__ __forceinline__ f32x2 pe_mad(f32x2 a, float b, f32x2 c)
+{
+    if constexpr (FUSE) return __builtin_elementwise_fma(a, f32x2{b, b}, c);
+    else return a * b + c;
+}
+template <int N, int TH, int F32ACC = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) void tw_polyexp_pk(PolyArgs a)
 {
+    constexpr bool FUSE = F32ACC == 2;
     constexpr int RP = TH / 2, NW = TH + 2 * N, NPA = NW / 2, NPB = NW / 2 - 1;
     static_assert(NW % 2 == 0 && PE_TW % 2 == 0 && N <= PE_HALO - 1, "tile shape");
     __shared__ __attribute__((aligned(16))) f32x2 sm[3][RP][PE_COLS];
@@ -918,9 +927,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
                 const f32x2 s0 = P(ci - k), s1 = P(ci + k);  // rows y-k, y+k
                 const f32x2 p = s0 + s1;
                 const f32x2 d = s1 - s0;
-                t0 = t0 + c.g[k] * p;
-                t1 = t1 + c.xg[k] * d;
-                t2 = t2 + c.xxg[k] * p;
+                t0 = pe_mad<FUSE>(p, c.g[k], t0);
+                t1 = pe_mad<FUSE>(d, c.xg[k], t1);
+                t2 = pe_mad<FUSE>(p, c.xxg[k], t2);
             }
             sm[0][rp][tid] = t0;
             sm[1][rp][tid] = t1;
@@ -947,7 +956,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
             }
         };
         f32x2 o[5][2];    // [plane][row q] = {pixel 0, pixel 1}
-        if constexpr (F32ACC) {
+        if constexpr (F32ACC != 0) {
             // all-float horizontal pass, packed over the row pair; same tap order as the double version
             const float ig11 = (float)c.ig11, ig03 = (float)c.ig03, ig33 = (float)c.ig33, ig55 = (float)c.ig55;
             f32x2 p03f[2];
@@ -960,12 +969,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
                 for (int k = 1; k <= N; k++) {
                     const f32x2 tg = v[li + k] + v[li - k];
                     const f32x2 dd = v[li + k] - v[li - k];
-                    b1 = b1 + tg * c.g[k];
-                    b4 = b4 + tg * c.xxg[k];
-                    b2 = b2 + dd * c.xg[k];
+                    b1 = pe_mad<FUSE>(tg, c.g[k], b1);
+                    b4 = pe_mad<FUSE>(tg, c.xxg[k], b4);
+                    b2 = pe_mad<FUSE>(dd, c.xg[k], b2);
                 }
                 p03f[j] = b1 * ig03;
-                const f32x2 r1 = b2 * ig11, r3 = p03f[j] + b4 * ig33;
+                const f32x2 r1 = b2 * ig11, r3 = pe_mad<FUSE>(b4, ig33, p03f[j]);
                 o[1][0][j] = r1[0]; o[1][1][j] = r1[1];
                 o[3][0][j] = r3[0]; o[3][1][j] = r3[1];
             }
@@ -977,8 +986,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
                 f32x2 b3 = v[li] * c.g[0], b6 = f32x2{0.f, 0.f};
 #pragma unroll
                 for (int k = 1; k <= N; k++) {
-                    b3 = b3 + (v[li + k] + v[li - k]) * c.g[k];
-                    b6 = b6 + (v[li + k] - v[li - k]) * c.xg[k];
+                    b3 = pe_mad<FUSE>(v[li + k] + v[li - k], c.g[k], b3);
+                    b6 = pe_mad<FUSE>(v[li + k] - v[li - k], c.xg[k], b6);
                 }
                 const f32x2 r0 = b3 * ig11, r4 = b6 * ig55;
                 o[0][0][j] = r0[0]; o[0][1][j] = r0[1];
@@ -991,8 +1000,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
                 const int li = PE_HALO + j;
                 f32x2 b5 = v[li] * c.g[0];
 #pragma unroll
-                for (int k = 1; k <= N; k++) b5 = b5 + (v[li + k] + v[li - k]) * c.g[k];
-                const f32x2 r2 = p03f[j] + b5 * ig33;
+                for (int k = 1; k <= N; k++) b5 = pe_mad<FUSE>(v[li + k] + v[li - k], c.g[k], b5);
+                const f32x2 r2 = pe_mad<FUSE>(b5, ig33, p03f[j]);
                 o[2][0][j] = r2[0]; o[2][1][j] = r2[1];
             }
         } else {

@@ -20,13 +20,16 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 python3 tools/pmc_traffic.py "$out/pmc_FETCH_SIZE" "$out/pmc_WRITE_SIZE" "$out/traffic.json" "$out/pmc_hbm_traffic.md"
 tools/sq_probe.sh "$out/sq_polyexp" 8 1 0 > "$out/sq_polyexp.txt" 2>&1
-TW_POLY_VARIANT=0 tools/sq_probe.sh "$out/sq_polyexp_scalar" 8 1 0 > "$out/sq_polyexp_scalar.txt" 2>&1
+TW_POLYEXP_F32=1 tools/sq_probe.sh "$out/sq_polyexp_f32" 8 1 0 > "$out/sq_polyexp_f32.txt" 2>&1
+TW_POLYEXP_F32=2 tools/sq_probe.sh "$out/sq_polyexp_f32f" 8 1 0 > "$out/sq_polyexp_f32f.txt" 2>&1
 tools/sq_probe.sh "$out/sq_blur_fused" 8 3 0 0 > "$out/sq_blur_fused.txt" 2>&1
 tools/sq_probe.sh "$out/sq_blur_last" 8 3 0 2 > "$out/sq_blur_last.txt" 2>&1
-python3 tools/sq_report.py "$out/sq_polyexp" tw_polyexp_pk 265420800 "tw_polyexp_pk<7,8> @ level 0, 64 pairs (128 images of 1920x1080) per launch" packed > "$out/polyexp_sq.md"
-python3 tools/sq_report.py "$out/sq_polyexp_scalar" "tw_polyexp<7>" 265420800 "tw_polyexp<7> (scalar f32, TW_POLY_VARIANT=0) @ level 0, 64 pairs per launch" > "$out/polyexp_scalar_sq.md"
+python3 tools/sq_report.py "$out/sq_polyexp" "tw_polyexp_pk<7, 8, 0>" 265420800 "tw_polyexp_pk<7,8> @ level 0, 64 pairs (128 images of 1920x1080) per launch" packed > "$out/polyexp_sq.md"
+python3 tools/sq_report.py "$out/sq_polyexp_f32" "tw_polyexp_pk<7, 8, 1>" 265420800 "tw_polyexp_pk<7,8,1> (measurement variant TW_OPT_POLYEXP_F32 = 1: float horizontal accumulators, NOT bit-exact) @ level 0, 64 pairs per launch" packed > "$out/polyexp_f32_sq.md"
+python3 tools/sq_report.py "$out/sq_polyexp_f32f" "tw_polyexp_pk<7, 8, 2>" 265420800 "tw_polyexp_pk<7,8,2> (measurement variant TW_OPT_POLYEXP_F32 = 2: float accumulators AND fused multiply-adds, NOT bit-exact) @ level 0, 64 pairs per launch" packed > "$out/polyexp_f32_fused_sq.md"
 python3 tools/sq_report.py "$out/sq_blur_fused" tw_blur_solve4 132710400 "tw_blur_solve4<15,256,16,8> fused with the matrix refresh @ level 0, 64 pairs per launch" > "$out/blur_fused_sq.md"
 python3 tools/sq_report.py "$out/sq_blur_last" tw_blur_solve4 132710400 "tw_blur_solve4<15,256,16,8> last iteration (no refresh) @ level 0, 64 pairs per launch" > "$out/blur_last_sq.md"
 python3 tools/clock_watch.py "$out/clock_power.json" -- python3 bench.py --steps 40 --warmup 4 --no-cpu-baseline --no-extras > "$out/clock_power.log" 2>&1
 python3 tools/latency.py 40 > "$out/latency.txt" 2>&1
+python3 tools/polyexp_f32.py > "$out/polyexp_f32.json" 2> "$out/polyexp_f32.err"
 echo done; cut -c1-400 "$out/bench.json"

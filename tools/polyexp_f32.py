@@ -56,7 +56,7 @@ def main():
 
     with T.Engine(0, T.default_params(), slots=n_img) as e:
         by = e.algorithmic_bytes(T.K_POLYEXP, 0, W, H) / 2 * n_img  # 24 B/px per image
-        for name, opt in (("f64_exact", 0), ("f32_variant", 1)):
+        for name, opt in (("f64_exact", 0), ("f32_variant", 1), ("f32_fused_variant", 2)):
             e.set_option(T.OPT_POLYEXP_F32, opt)
             us = min(e.bench_stage(T.K_POLYEXP, W, H, 0, n_img // 2, 30, 0) for _ in range(3))
             out["timing"][name] = {"us_per_launch": round(us, 1), "images_per_launch": n_img,
@@ -70,21 +70,28 @@ def main():
             e.set_option(T.OPT_POLYEXP_F32, 0)
             gx, gy, _ = e.calculate_internal(a, b)
             exact_equal = bool(np.array_equal(gx, wx) and np.array_equal(gy, wy))
+            e.set_option(T.OPT_POLYEXP_F32, 2)
+            ux, uy, _ = e.calculate_internal(a, b)
+            res2 = e.diff(a, b, 10, 5.0)
             e.set_option(T.OPT_POLYEXP_F32, 1)
             fx, fy, _ = e.calculate_internal(a, b)
             res = e.diff(a, b, 10, 5.0)
             e.set_option(T.OPT_POLYEXP_F32, 0)
             err = max(float(np.abs(fx - wx).max()), float(np.abs(fy - wy).max()))
+            err2 = max(float(np.abs(ux - wx).max()), float(np.abs(uy - wy).max()))
             mag = np.hypot(wx, wy)
             ident = res["vector"] == want
             nd = sum(1 for p, q in zip(res["vector"], want) if p != q) + abs(len(res["vector"]) - len(want))
             out["flow"].append({"pair": name, "exact_engine_equals_oracle": exact_equal,
-                                "max_abs_flow_err": err, "p999_abs_err": float(np.quantile(
+                                "max_abs_flow_err": err, "max_abs_flow_err_fused": err2,
+                                "vectors_identical_fused": bool(res2["vector"] == want), "p999_abs_err": float(np.quantile(
                                     np.maximum(np.abs(fx - wx), np.abs(fy - wy)), 0.999)),
                                 "max_flow_magnitude": float(mag.max()),
                                 "vectors": len(want), "vectors_identical": bool(ident), "vectors_differing": int(nd),
                                 "same_positions": [(p[0], p[1]) for p in res["vector"]] == [(q[0], q[1]) for q in want]})
     out["summary"] = {"frac": out["timing"]["f32_variant"]["frac_of_8TBps"],
+                      "frac_fused": out["timing"]["f32_fused_variant"]["frac_of_8TBps"],
+                      "max_abs_flow_err_fused": max(f["max_abs_flow_err_fused"] for f in out["flow"]),
                       "frac_exact": out["timing"]["f64_exact"]["frac_of_8TBps"],
                       "max_abs_flow_err": max(f["max_abs_flow_err"] for f in out["flow"]),
                       "vectors_identical": all(f["vectors_identical"] for f in out["flow"])}
