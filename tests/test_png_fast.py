@@ -187,8 +187,8 @@ def test_png_unfilter_every_type_and_paeth_runs(lib, bpp):
         assert lib.twt_unfilter(buf, rowbytes, rows, bpp) == 1
         got = np.frombuffer(buf.raw, np.uint8).reshape(rows, rowbytes + 1)[:, 1:]
         assert np.array_equal(got, want), (bpp, rowbytes, rows)
-    # all-Paeth image (odd and even row counts), and an invalid filter type
-    for rows in (1, 2, 7, 8):
+    # all-Paeth image (row counts around the 2- / 4- / 8- / 16-row wavefront group sizes), and an invalid filter type
+    for rows in (1, 2, 7, 8, 9, 16, 17, 25, 40):
         raw = rng.integers(0, 256, (rows, 1 + 53 * bpp), dtype=np.uint8)
         raw[:, 0] = 4
         buf = C.create_string_buffer(raw.tobytes(), raw.size)

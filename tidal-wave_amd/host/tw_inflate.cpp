@@ -15,6 +15,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <vector>
+
 #if defined(__x86_64__)
 #include <immintrin.h>
 #endif
@@ -626,6 +628,100 @@ static void paeth_rowsK_bpp1(uint8_t* r0, size_t pitch, const uint8_t* prev, siz
         for (int k = K - 1; k > (int)(i - n); k--) step(k, i - (size_t)k);
 }
 
+#if defined(__x86_64__)
+// 8 * G consecutive Paeth rows of a 1-byte-per-pixel image as a SIMD wavefront (16-bit lanes, G registers): at step s
+// lane k decodes column s - k of row k.  Its left neighbour is the lane's own previous result, its upper neighbour the
+// result lane k-1 produced one step earlier (one lane shift of the previous result vectors; lane 0 reads the row above),
+// its upper-left neighbour the upper neighbour of the step before.  The filtered bytes reach the lanes through skewed
+// scratch copies of the rows (row k shifted right by 8G-1-k, zero padded) and 8x8 byte transposes per eight steps; the
+// results leave the same way.  ~3 vector operations per byte instead of ~15 scalar ones; with G = 2 the two registers'
+// dependency chains overlap.
+template <int G>
+__attribute__((target("ssse3"))) static void paeth_rows_ssse3(uint8_t* r0, size_t pitch, const uint8_t* prev, size_t n)
+{
+    constexpr int K = 8 * G, SK = K - 1;
+    const size_t steps = n + SK, nblk = (steps + 7) / 8, len = 8 * nblk + 8 + K;
+    static thread_local std::vector<uint8_t> scratch;
+    if (scratch.size() < (2 * K + 1) * len) scratch.resize((2 * K + 1) * len);
+    uint8_t* in = scratch.data();
+    uint8_t* out = in + (size_t)K * len;
+    uint8_t* up = out + (size_t)K * len;
+    for (int k = 0; k < K; k++) {
+        uint8_t* d = in + (size_t)k * len;
+        memset(d, 0, SK);
+        memcpy(d + SK, r0 + pitch * (size_t)k, n);
+        memset(d + SK + n, 0, len - SK - n);
+    }
+    memcpy(up, prev, n);
+    memset(up + n, 0, len - n);
+    const __m128i zero = _mm_setzero_si128(), ff = _mm_set1_epi16(0xff);
+    __m128i A[G], Bp[G];  // results of the previous step; the upper neighbours the previous step used
+    for (int g = 0; g < G; g++) A[g] = Bp[g] = zero;
+    // lanes that have not reached column 0 yet must stay at zero: lane k is active from step k on
+    alignas(16) int16_t ramp[K][K];
+    for (int st = 0; st < K; st++)
+        for (int k = 0; k < K; k++) ramp[st][k] = k <= st ? -1 : 0;
+    for (size_t blk = 0; blk < nblk; blk++) {
+        const size_t s0 = 8 * blk;
+        __m128i v[G][4];  // v[g][i] = lanes 8g..8g+7 at steps 2i (low half) and 2i + 1 (high half)
+        for (int g = 0; g < G; g++) {
+            __m128i r[8];
+            for (int k = 0; k < 8; k++)
+                r[k] = _mm_loadl_epi64((const __m128i*)(in + (size_t)(8 * g + k) * len + SK + s0 - (size_t)(8 * g + k)));
+            const __m128i t0 = _mm_unpacklo_epi8(r[0], r[1]), t1 = _mm_unpacklo_epi8(r[2], r[3]);
+            const __m128i t2 = _mm_unpacklo_epi8(r[4], r[5]), t3 = _mm_unpacklo_epi8(r[6], r[7]);
+            const __m128i u0 = _mm_unpacklo_epi16(t0, t1), u1 = _mm_unpackhi_epi16(t0, t1);
+            const __m128i u2 = _mm_unpacklo_epi16(t2, t3), u3 = _mm_unpackhi_epi16(t2, t3);
+            v[g][0] = _mm_unpacklo_epi32(u0, u2);
+            v[g][1] = _mm_unpackhi_epi32(u0, u2);
+            v[g][2] = _mm_unpacklo_epi32(u1, u3);
+            v[g][3] = _mm_unpackhi_epi32(u1, u3);
+        }
+        __m128i w[G][4];
+        for (int i = 0; i < 4; i++) {
+            __m128i res[G][2];
+            for (int h = 0; h < 2; h++) {
+                const size_t s = s0 + 2 * (size_t)i + (size_t)h;
+                __m128i B[G];
+                B[0] = _mm_insert_epi16(_mm_slli_si128(A[0], 2), up[s], 0);
+                for (int g = 1; g < G; g++) B[g] = _mm_alignr_epi8(A[g], A[g - 1], 14);
+                for (int g = 0; g < G; g++) {
+                    const __m128i X = h ? _mm_unpackhi_epi8(v[g][i], zero) : _mm_unpacklo_epi8(v[g][i], zero);
+                    const __m128i C = Bp[g];
+                    const __m128i d = _mm_sub_epi16(B[g], C), t = _mm_sub_epi16(A[g], C);
+                    const __m128i pa = _mm_abs_epi16(d), pb = _mm_abs_epi16(t), pc = _mm_abs_epi16(_mm_add_epi16(t, d));
+                    const __m128i mc = _mm_cmpgt_epi16(pb, pc);  // pb > pc: c, else b
+                    const __m128i bc = _mm_or_si128(_mm_and_si128(mc, C), _mm_andnot_si128(mc, B[g]));
+                    const __m128i mn = _mm_or_si128(_mm_cmpgt_epi16(pa, pb), _mm_cmpgt_epi16(pa, pc));  // not a
+                    const __m128i pr = _mm_or_si128(_mm_and_si128(mn, bc), _mm_andnot_si128(mn, A[g]));
+                    __m128i R = _mm_and_si128(_mm_add_epi16(X, pr), ff);
+                    if (s < (size_t)SK) R = _mm_and_si128(R, _mm_load_si128((const __m128i*)&ramp[s][8 * g]));
+                    Bp[g] = B[g];
+                    res[g][h] = R;
+                }
+                for (int g = 0; g < G; g++) A[g] = res[g][h];
+            }
+            for (int g = 0; g < G; g++) w[g][i] = _mm_packus_epi16(res[g][0], res[g][1]);
+        }
+        for (int g = 0; g < G; g++) {
+            const __m128i a0 = _mm_unpacklo_epi8(w[g][0], _mm_srli_si128(w[g][0], 8));
+            const __m128i a1 = _mm_unpacklo_epi8(w[g][1], _mm_srli_si128(w[g][1], 8));
+            const __m128i a2 = _mm_unpacklo_epi8(w[g][2], _mm_srli_si128(w[g][2], 8));
+            const __m128i a3 = _mm_unpacklo_epi8(w[g][3], _mm_srli_si128(w[g][3], 8));
+            const __m128i b0 = _mm_unpacklo_epi16(a0, a1), b1 = _mm_unpackhi_epi16(a0, a1);
+            const __m128i b2 = _mm_unpacklo_epi16(a2, a3), b3 = _mm_unpackhi_epi16(a2, a3);
+            const __m128i c[4] = {_mm_unpacklo_epi32(b0, b2), _mm_unpackhi_epi32(b0, b2), _mm_unpacklo_epi32(b1, b3),
+                                  _mm_unpackhi_epi32(b1, b3)};  // c[i] = rows 2i (low half) and 2i + 1 (high half)
+            for (int k = 0; k < 8; k++) {
+                const __m128i row = (k & 1) ? _mm_srli_si128(c[k >> 1], 8) : c[k >> 1];
+                _mm_storel_epi64((__m128i*)(out + (size_t)(8 * g + k) * len + SK + s0 - (size_t)(8 * g + k)), row);
+            }
+        }
+    }
+    for (int k = 0; k < K; k++) memcpy(r0 + pitch * (size_t)k, out + (size_t)k * len + SK, n);
+}
+#endif
+
 bool tw_png_unfilter_row(int ft, uint8_t* cur, const uint8_t* pv, size_t rowbytes, size_t fbpp)
 {
     const size_t head = fbpp < rowbytes ? fbpp : rowbytes;
@@ -672,7 +768,21 @@ bool tw_png_unfilter(uint8_t* raw, size_t rowbytes, size_t rows, size_t fbpp)
         const uint8_t* pv = y ? raw + pitch * (y - 1) + 1 : nullptr;
         if (fbpp == 1 && pv && row[0] == 4) {
             size_t run = 1;
-            while (run < 4 && y + run < rows && row[pitch * run] == 4) run++;
+            while (run < 16 && y + run < rows && row[pitch * run] == 4) run++;
+#if defined(__x86_64__)
+            static const bool simd = __builtin_cpu_supports("ssse3") && !getenv("TW_PNG_SCALAR");
+            if (run == 16 && simd && rowbytes >= 32) {
+                paeth_rows_ssse3<2>(row + 1, pitch, pv, rowbytes);
+                y += 16;
+                continue;
+            }
+            if (run >= 8 && simd && rowbytes >= 16) {
+                paeth_rows_ssse3<1>(row + 1, pitch, pv, rowbytes);
+                y += 8;
+                continue;
+            }
+#endif
+            if (run > 4) run = 4;
             if (run == 4) {  // (measured: 2 rows 3.9 ms, 4 rows 3.3 ms, 8 rows 3.8-4.8 ms per 1080p image)
                 paeth_rowsK_bpp1<4>(row + 1, pitch, pv, rowbytes);
                 y += 4;
