@@ -300,6 +300,12 @@ def test_image_decoders_survive_mutated_files_under_asan(tmp_path):
     seeds = [os.path.join(g, "tree", "expected", "scenario2", "capture2.png"),
              os.path.join(g, "tree", "expected", "scenario1", "capture1.jpg"),
              os.path.join(g, "expected_scenario2_capture2.pgm"), gray_png]
+    for name in ("c.bmp", "c.ppm"):  # OpenCV-decoder formats (round 3)
+        Image.fromarray(np.dstack([synth.make_pair(2, 48, 64)[0]] * 3)).save(str(tmp_path / name))
+        seeds.append(str(tmp_path / name))
+    pal = Image.fromarray(synth.make_pair(2, 48, 64)[0]).convert("P")
+    pal.save(str(tmp_path / "p.bmp"))
+    seeds.append(str(tmp_path / "p.bmp"))
     r = subprocess.run([os.path.join(HOST, "build", "fuzz_decode"), "1500", str(tmp_path / "scratch.bin")] + seeds,
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]

@@ -298,3 +298,59 @@ print("asan inflate fuzz accepted", tot)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=env)
     assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]
     assert r.returncode == 0 and "asan inflate fuzz accepted" in r.stdout, (r.stdout, r.stderr[-2000:])
+
+
+def _gray_cv(rgb):
+    """OpenCV 2.4.9's own decoders (BMP, PxM): icvCvt_BGR2Gray_8u_C3C1R — 14-bit coefficients, rounded."""
+    r, g, b = (rgb[..., i].astype(np.int64) for i in range(3))
+    return ((b * 1868 + g * 9617 + r * 4899 + (1 << 13)) >> 14).astype(np.uint8)
+
+
+def test_bmp_and_pnm_files(lib, tmp_path):
+    """cv::imread reads BMP and PBM / PGM / PPM with OpenCV's own decoders (src/opticalflow.cpp:37,44; highgui's
+    grfmt_bmp.cpp / grfmt_pxm.cpp), whose colour -> gray formula differs from libpng's.  No fixture of the reference
+    is such a file: PARITY UNPINNED — the check is against PIL's decode of the same file + that formula."""
+    from PIL import Image
+    rng = np.random.default_rng(4)
+    rgb = rng.integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    gray = rng.integers(0, 256, (37, 53), dtype=np.uint8)
+    # BMP: 24-bit, 32-bit, 8-bit palette (gray and colour), 1-bit
+    Image.fromarray(rgb).save(tmp_path / "c24.bmp")
+    assert np.array_equal(_load(lib, tmp_path / "c24.bmp"), _gray_cv(rgb))
+    Image.fromarray(np.dstack([rgb, gray])).save(tmp_path / "c32.bmp")
+    back = np.asarray(Image.open(tmp_path / "c32.bmp").convert("RGB"))
+    assert np.array_equal(_load(lib, tmp_path / "c32.bmp"), _gray_cv(back))
+    Image.fromarray(gray).save(tmp_path / "g8.bmp")
+    assert np.array_equal(_load(lib, tmp_path / "g8.bmp"), _gray_cv(np.dstack([gray] * 3)))
+    pal = Image.fromarray(rgb).convert("P", palette=Image.ADAPTIVE, colors=200)
+    pal.save(tmp_path / "p8.bmp")
+    assert np.array_equal(_load(lib, tmp_path / "p8.bmp"), _gray_cv(np.asarray(pal.convert("RGB"))))
+    bw = Image.fromarray(gray > 127)
+    bw.save(tmp_path / "b1.bmp")
+    assert np.array_equal(_load(lib, tmp_path / "b1.bmp"), _gray_cv(np.asarray(Image.open(tmp_path / "b1.bmp").convert("RGB"))))
+    # PNM: P6 / P5 / P4 as PIL writes them; ASCII kinds and a maxval below 255 by hand
+    Image.fromarray(rgb).save(tmp_path / "c.ppm")
+    assert np.array_equal(_load(lib, tmp_path / "c.ppm"), _gray_cv(rgb))
+    Image.fromarray(gray).save(tmp_path / "g.pgm")
+    assert np.array_equal(_load(lib, tmp_path / "g.pgm"), gray)
+    bw.save(tmp_path / "b.pbm")
+    assert np.array_equal(_load(lib, tmp_path / "b.pbm"), np.where(np.asarray(bw), 255, 0).astype(np.uint8))
+    small = rng.integers(0, 16, (5, 7), dtype=np.uint8)
+    (tmp_path / "a2.pgm").write_text("P2\n# comment\n7 5\n15\n" + "\n".join(" ".join(map(str, r)) for r in small) + "\n")
+    assert np.array_equal(_load(lib, tmp_path / "a2.pgm"), (small.astype(int) * 255 // 15).astype(np.uint8))
+    c3 = rng.integers(0, 256, (4, 6, 3), dtype=np.uint8)
+    (tmp_path / "a3.ppm").write_text("P3 6 4 255\n" + " ".join(map(str, c3.ravel())) + "\n")
+    assert np.array_equal(_load(lib, tmp_path / "a3.ppm"), _gray_cv(c3))
+    (tmp_path / "a1.pbm").write_text("P1\n4 2\n0110\n1 0 0 1\n")
+    assert np.array_equal(_load(lib, tmp_path / "a1.pbm"), np.array([[255, 0, 0, 255], [0, 255, 255, 0]], np.uint8))
+    # damaged / unsupported files are rejected
+    d = bytearray((tmp_path / "c24.bmp").read_bytes())
+    (tmp_path / "short.bmp").write_bytes(bytes(d[:200]))
+    assert _load(lib, tmp_path / "short.bmp") is None
+    d[30] = 1  # BI_RLE8
+    (tmp_path / "rle.bmp").write_bytes(bytes(d))
+    assert _load(lib, tmp_path / "rle.bmp") is None
+    (tmp_path / "big.pgm").write_bytes(b"P5 4 4 65535\n" + bytes(32))
+    assert _load(lib, tmp_path / "big.pgm") is None
+    (tmp_path / "trunc.ppm").write_bytes(b"P6 10 10 255\n" + bytes(100))
+    assert _load(lib, tmp_path / "trunc.ppm") is None

@@ -138,31 +138,141 @@ static bool read_file(const std::string& path, std::vector<uint8_t>& buf)
     return got == (size_t)n;
 }
 
-static bool decode_pgm(const std::vector<uint8_t>& d, std::vector<uint8_t>& img, int& w, int& h)
+// OpenCV 2.4.9's own decoders (BMP, PxM) convert colour to gray with icvCvt_BGR2Gray_8u_C3C1R (highgui/utils.cpp):
+// 14-bit coefficients, rounded — NOT libpng's formula.  No fixture of the reference is a BMP or a PNM: parity unpinned.
+static inline uint8_t bgr_to_gray_cv(int b, int g, int r)
 {
+    return (uint8_t)((b * 1868 + g * 9617 + r * 4899 + (1 << 13)) >> 14);
+}
+
+// PBM / PGM / PPM, binary and ASCII (P1-P6), maxval <= 255 (highgui/grfmt_pxm.cpp: values are scaled by 255 / maxval,
+// bitmaps read 1 as black)
+static bool decode_pnm(const std::vector<uint8_t>& d, std::vector<uint8_t>& img, int& w, int& h)
+{
+    const int kind = d[1] - '0';
+    if (kind < 1 || kind > 6) return false;
     size_t p = 2;
-    int vals[3], nv = 0;
-    while (nv < 3 && p < d.size()) {
-        while (p < d.size() && (d[p] == ' ' || d[p] == '\n' || d[p] == '\r' || d[p] == '\t')) p++;
-        if (p < d.size() && d[p] == '#') {
-            while (p < d.size() && d[p] != '\n') p++;
-            continue;
+    auto skip = [&] {
+        for (;;) {
+            while (p < d.size() && (d[p] == ' ' || d[p] == '\n' || d[p] == '\r' || d[p] == '\t')) p++;
+            if (p < d.size() && d[p] == '#') {
+                while (p < d.size() && d[p] != '\n') p++;
+                continue;
+            }
+            return;
         }
-        int v = 0, nd = 0;
-        while (p < d.size() && d[p] >= '0' && d[p] <= '9') {
-            v = v * 10 + (d[p] - '0');
+    };
+    auto number = [&](int& v) -> bool {
+        skip();
+        long long acc = 0;
+        int nd = 0;
+        while (p < d.size() && d[p] >= '0' && d[p] <= '9' && nd < 10) {
+            acc = acc * 10 + (d[p] - '0');
             p++;
             nd++;
         }
-        if (!nd) return false;
-        vals[nv++] = v;
+        if (!nd || acc > 0x7fffffff) return false;
+        v = (int)acc;
+        return true;
+    };
+    const bool bitmap = kind == 1 || kind == 4, colour = kind == 3 || kind == 6, ascii = kind <= 3;
+    int maxval = 1;
+    if (!number(w) || !number(h) || (!bitmap && !number(maxval))) return false;
+    if (w < 1 || h < 1 || w > 32768 || h > 32768 || maxval < 1 || maxval > 255) return false;
+    if (!ascii) p++;  // a single whitespace byte ends the header of the binary kinds
+    const size_t npx = (size_t)w * h;
+    img.resize(npx);
+    uint8_t scale[256];
+    for (int i = 0; i <= maxval; i++) scale[i] = (uint8_t)(i * 255 / maxval);
+    if (ascii) {
+        for (size_t i = 0; i < npx; i++) {
+            int v[3] = {0, 0, 0};
+            for (int c = 0; c < (colour ? 3 : 1); c++) {
+                if (bitmap) {  // digits need no separators in P1
+                    skip();
+                    if (p >= d.size() || (d[p] != '0' && d[p] != '1')) return false;
+                    v[c] = d[p++] - '0';
+                } else if (!number(v[c]) || v[c] > maxval) {
+                    return false;
+                }
+            }
+            img[i] = bitmap ? (v[0] ? 0 : 255) : colour ? bgr_to_gray_cv(scale[v[2]], scale[v[1]], scale[v[0]]) : scale[v[0]];
+        }
+        return true;
     }
-    if (nv < 3 || vals[2] != 255 || vals[0] < 1 || vals[1] < 1) return false;
-    p++;  // single whitespace after maxval
-    w = vals[0];
-    h = vals[1];
-    if (p + (size_t)w * h > d.size()) return false;
-    img.assign(d.begin() + p, d.begin() + p + (size_t)w * h);
+    if (bitmap) {
+        const size_t rb = ((size_t)w + 7) / 8;
+        if (p + rb * h > d.size()) return false;
+        for (int y = 0; y < h; y++)
+            for (int x = 0; x < w; x++) img[(size_t)y * w + x] = (d[p + rb * y + (x >> 3)] >> (7 - (x & 7))) & 1 ? 0 : 255;
+        return true;
+    }
+    const size_t need = npx * (colour ? 3 : 1);
+    if (p + need > d.size()) return false;
+    const uint8_t* q = &d[p];
+    for (size_t i = 0; i < npx; i++) {
+        if (colour) {
+            if (q[3 * i] > maxval || q[3 * i + 1] > maxval || q[3 * i + 2] > maxval) return false;
+            img[i] = bgr_to_gray_cv(scale[q[3 * i + 2]], scale[q[3 * i + 1]], scale[q[3 * i]]);
+        } else {
+            if (q[i] > maxval) return false;
+            img[i] = scale[q[i]];
+        }
+    }
+    return true;
+}
+
+// Windows / OS/2 bitmaps, uncompressed: 1 / 4 / 8 bits with a palette, 24 and 32 bits (highgui/grfmt_bmp.cpp reads RLE4 /
+// RLE8 and 16-bit files as well: those answer "Can't open" here)
+static bool decode_bmp(const std::vector<uint8_t>& d, std::vector<uint8_t>& img, int& w, int& h)
+{
+    auto u16 = [&](size_t o) { return (uint32_t)d[o] | ((uint32_t)d[o + 1] << 8); };
+    auto u32 = [&](size_t o) { return u16(o) | (u16(o + 2) << 16); };
+    if (d.size() < 26) return false;
+    const uint32_t off = u32(10), hs = u32(14);
+    int bpp, comp = 0;
+    bool topdown = false;
+    size_t pal_entry = 4;
+    if (hs == 12) {  // OS/2 core header: 16-bit sizes, 3-byte palette entries
+        w = (int)u16(18);
+        h = (int)u16(20);
+        bpp = (int)u16(24);
+        pal_entry = 3;
+    } else if (hs >= 40 && d.size() >= 14 + 40) {
+        w = (int)u32(18);
+        int hh = (int)u32(22);
+        topdown = hh < 0;
+        h = topdown ? -hh : hh;
+        bpp = (int)u16(28);
+        comp = (int)u32(30);
+    } else {
+        return false;
+    }
+    if (w < 1 || h < 1 || w > 32768 || h > 32768) return false;
+    if (comp != 0 || !(bpp == 1 || bpp == 4 || bpp == 8 || bpp == 24 || bpp == 32)) return false;
+    uint8_t pal[256];
+    if (bpp <= 8) {
+        const size_t po = 14 + (size_t)hs;
+        uint32_t ncol = hs >= 40 ? u32(46) : 0;
+        if (ncol == 0 || ncol > (1u << bpp)) ncol = 1u << bpp;
+        if (po + pal_entry * ncol > d.size()) return false;
+        memset(pal, 0, sizeof(pal));
+        for (uint32_t i = 0; i < ncol; i++) pal[i] = bgr_to_gray_cv(d[po + pal_entry * i], d[po + pal_entry * i + 1], d[po + pal_entry * i + 2]);
+    }
+    const size_t stride = (((size_t)w * bpp + 31) / 32) * 4;
+    if ((size_t)off + stride * h > d.size() || off < 14 + hs) return false;
+    img.resize((size_t)w * h);
+    for (int y = 0; y < h; y++) {
+        const uint8_t* row = &d[(size_t)off + stride * (size_t)(topdown ? y : h - 1 - y)];
+        uint8_t* out = &img[(size_t)y * w];
+        for (int x = 0; x < w; x++) {
+            if (bpp == 24) out[x] = bgr_to_gray_cv(row[3 * x], row[3 * x + 1], row[3 * x + 2]);
+            else if (bpp == 32) out[x] = bgr_to_gray_cv(row[4 * x], row[4 * x + 1], row[4 * x + 2]);
+            else if (bpp == 8) out[x] = pal[row[x]];
+            else if (bpp == 4) out[x] = pal[(row[x >> 1] >> ((x & 1) ? 0 : 4)) & 15];
+            else out[x] = pal[(row[x >> 3] >> (7 - (x & 7))) & 1];
+        }
+    }
     return true;
 }
 
@@ -296,10 +406,11 @@ bool load_gray(const std::string& path, std::vector<uint8_t>& img, int& w, int& 
 {
     std::vector<uint8_t> d;
     if (!read_file(path, d) || d.size() < 8) return false;
-    if (d[0] == 'P' && d[1] == '5') return decode_pgm(d, img, w, h);
+    if (d[0] == 'P' && d[1] >= '1' && d[1] <= '6') return decode_pnm(d, img, w, h);
     if (d[0] == 0x89 && d[1] == 'P') return decode_png(d, img, w, h);
     if (d[0] == 0xFF && d[1] == 0xD8) return decode_jpeg_gray(d.data(), d.size(), img, w, h);
-    return false;  // the other cv::imread formats (BMP, TIFF, JPEG-2000, ...) are not decoded
+    if (d[0] == 'B' && d[1] == 'M') return decode_bmp(d, img, w, h);
+    return false;  // the other cv::imread formats (TIFF, JPEG-2000, Sun raster, ...) are not decoded
 }
 
 // cv::resize on CV_8UC1, INTER_LINEAR, 11-bit fixed point (imgproc/imgwarp.cpp: HResizeLinear<uchar,int,short>,
