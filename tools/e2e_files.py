@@ -32,7 +32,9 @@ def main():
     js = ("var T=require('./index'); var t0=Date.now(); var n=0;"
           "var t=T.create(process.argv[1],{expectDir:process.argv[2], numThreads:8});"
           "t.on('data',function(){n++}); t.on('error',function(e){console.error(JSON.stringify(e))});"
-          "t.on('finish',function(r){console.log(JSON.stringify({report:r, ms:Date.now()-t0}))});")
+          "var rss0=process.memoryUsage().rss, rssMid=0; setTimeout(function(){rssMid=process.memoryUsage().rss}, 3000);"
+          "t.on('finish',function(r){console.log(JSON.stringify({report:r, ms:Date.now()-t0, rss_start_MB:rss0>>20, "
+          "rss_at_3s_MB:rssMid>>20, rss_end_MB:process.memoryUsage().rss>>20}))});")
     env = dict(os.environ)
     if threads:
         env["TW_DECODE_THREADS"] = threads
