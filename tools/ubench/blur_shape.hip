@@ -1,0 +1,182 @@
+// Micro-benchmark: the MEMORY SHAPE of the fused window-average + solve + refresh launch (tw_blur_solve4<15,256,16,8>)
+// with no arithmetic — what do its loads and stores alone cost on this MI355X?  Per 224x8 tile and 256 threads:
+//   V  each lane loads the 38-row window of its column in each of the 5 M planes (190 loads, rows shared with the
+//      tiles above / below: L2 hits), raw buffer loads like the real kernel
+//   S  each lane, for 7 pixels: R0 (5 loads), the 2x2 R1 taps at zero flow (20 loads), 5 M stores
+// Modes: 0 = V + S (the refreshing launch: 80 B/px as built), 1 = V only + the 8 B/px flow store (the last launch:
+// 28 B/px), 2 = S only (the refresh's traffic alone: 60 B/px).  64 pairs of 1920x1080.
+// hipcc --offload-arch=gfx950 -O3 -w
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#pragma clang diagnostic ignored "-Wunused-value"
+constexpr int W = 1920, H = 1080, LD = 1920, TW = 224, TH = 8, MH = 15, HALO = 16, NW = TH + 2 * MH;
+__device__ __forceinline__ void xcd_remap(int& bx, int& by, int& bz)
+{
+    const unsigned gx = gridDim.x, gy = gridDim.y, n = gx * gy * gridDim.z;
+    unsigned b = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    const unsigned xcd = b & 7u, q = n >> 3, r = n & 7u;
+    b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+    bx = (int)(b % gx);
+    const unsigned t = b / gx;
+    by = (int)(t % gy);
+    bz = (int)(t / gy);
+}
+template <int MODE>
+__global__ __launch_bounds__(256) void k(const float* __restrict__ Min, const float* __restrict__ R, float* __restrict__ Mout,
+                                         float* __restrict__ flow, long long ps)
+{
+    int bx, by, z;
+    xcd_remap(bx, by, z);
+    const int x0 = bx * TW - 16, y0 = by * TH, tid = threadIdx.x;
+    float acc = 0.f;
+    if (MODE != 2) {
+        const float* M = Min + (long long)z * 5 * ps;
+        const int x = min(max(x0 - HALO + tid, 0), W - 1);
+        if (x0 - HALO + tid >= -MH && x0 - HALO + tid <= W - 1 + MH) {
+#pragma unroll
+            for (int ch = 0; ch < 5; ch++) {
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(M + ch * ps), 0, 0xFFFFFFFFu, 0x00020000);
+#pragma unroll
+                for (int i = 0; i < NW; i++) {
+                    const unsigned ro = (unsigned)min(max(y0 - MH + i, 0), H - 1) * (LD * 4u);
+                    acc += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (unsigned)x * 4u, ro, 0));
+                }
+            }
+        }
+    }
+    const float* R0 = R + (long long)(2 * z) * 5 * ps;
+    const float* R1 = R0 + 5 * ps;
+    float* Mo = Mout + (long long)z * 5 * ps;
+    float* fl = flow + (long long)z * 2 * ps;
+#pragma unroll
+    for (int i = 0; i < 7; i++) {
+        const int p = tid + i * 256, r = p / TW, cx = p - r * TW;
+        const int x = x0 + cx, y = y0 + r;
+        const bool valid = x >= 0 && x < W && y < H;
+        const int xc = min(max(x, 0), W - 2), yc = min(y, H - 2);
+        const long long o = (long long)yc * LD + xc;
+        if (MODE == 1) {
+            if (valid) {
+                fl[o] = acc;
+                fl[o + ps] = acc + 1.f;
+            }
+            continue;
+        }
+        float s = acc;
+#pragma unroll
+        for (int c = 0; c < 5; c++) {
+            s += R0[o + c * ps];
+            s += R1[o + c * ps] + R1[o + c * ps + 1] + R1[o + c * ps + LD] + R1[o + c * ps + LD + 1];
+        }
+        if (valid) {
+#pragma unroll
+            for (int c = 0; c < 5; c++) Mo[o + c * ps] = s + (float)c;
+        }
+    }
+}
+// window loads only, in other shapes: VEC floats per lane and load (b32 / b64 / b128: a wave then covers 64 * VEC columns),
+// ROWS output rows per tile (window = ROWS + 30 rows).  Same bytes per output row for a given ROWS.
+template <int VEC, int ROWS>
+__global__ __launch_bounds__(256) void kwin(const float* __restrict__ Min, float* __restrict__ out, long long ps)
+{
+    int bx, by, z;
+    xcd_remap(bx, by, z);
+    constexpr int TWV = 256 * VEC - 2 * HALO;
+    const int x0 = bx * TWV - 16, y0 = by * ROWS, tid = threadIdx.x;
+    const float* M = Min + (long long)z * 5 * ps;
+    const int x = min(max(x0 - HALO + tid * VEC, 0), W - VEC);
+    float acc = 0.f;
+    if (x0 - HALO + tid * VEC <= W - 1 + MH) {
+#pragma unroll
+        for (int ch = 0; ch < 5; ch++) {
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(M + ch * ps), 0, 0xFFFFFFFFu, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < ROWS + 2 * MH; i++) {
+                const unsigned ro = (unsigned)min(max(y0 - MH + i, 0), H - 1) * (LD * 4u);
+                if (VEC == 1) acc += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (unsigned)x * 4u, ro, 0));
+                if (VEC == 2) {
+                    typedef float __attribute__((ext_vector_type(2))) f2;
+                    const f2 v = __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(rs, (unsigned)x * 4u, ro, 0));
+                    acc += v[0] + v[1];
+                }
+                if (VEC == 4) {
+                    typedef float __attribute__((ext_vector_type(4))) f4;
+                    const f4 v = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)x * 4u, ro, 0));
+                    acc += v[0] + v[1] + v[2] + v[3];
+                }
+            }
+        }
+    }
+    if (acc == 12345.678f) out[0] = acc;
+}
+template <int VEC, int ROWS>
+static void run_win(const char* name, const float* M0, float* fl, long long ps, int np)
+{
+    constexpr int TWV = 256 * VEC - 2 * HALO;
+    const dim3 grid((W + 16 + TWV - 1) / TWV, (H + ROWS - 1) / ROWS, np);
+    double best = 1e30;
+    for (int rep = 0; rep < 2; rep++) {
+        hipEvent_t a, b;
+        hipEventCreate(&a);
+        hipEventCreate(&b);
+        hipLaunchKernelGGL((kwin<VEC, ROWS>), grid, dim3(256), 0, 0, M0, fl, ps);
+        hipEventRecord(a);
+        for (int i = 0; i < 10; i++) hipLaunchKernelGGL((kwin<VEC, ROWS>), grid, dim3(256), 0, 0, M0, fl, ps);
+        hipEventRecord(b);
+        hipEventSynchronize(b);
+        float ms = 0;
+        hipEventElapsedTime(&ms, a, b);
+        best = ms * 1e3 / 10 < best ? ms * 1e3 / 10 : best;
+    }
+    const double l1_bytes = 5.0 * 4 * W * H * np * (double)(ROWS + 30) / ROWS;
+    printf("window loads only, %-34s %8.1f us per 64 pairs  %6.2f us/pair  L2->L1 %5.1f TB/s\n", name, best, best / np, l1_bytes / best / 1e6);
+}
+template <typename F>
+static double time_us(F launch, int iters)
+{
+    hipEvent_t a, b;
+    hipEventCreate(&a);
+    hipEventCreate(&b);
+    launch();
+    launch();
+    hipEventRecord(a);
+    for (int i = 0; i < iters; i++) launch();
+    hipEventRecord(b);
+    hipEventSynchronize(b);
+    float ms = 0;
+    hipEventElapsedTime(&ms, a, b);
+    return ms * 1e3 / iters;
+}
+int main()
+{
+    const int np = 64;
+    const long long ps = (long long)LD * H;
+    float *M0, *M1, *R, *fl;
+    hipMalloc(&M0, ps * 5 * np * 4);
+    hipMalloc(&M1, ps * 5 * np * 4);
+    hipMalloc(&R, ps * 10 * np * 4);
+    hipMalloc(&fl, ps * 2 * np * 4);
+    hipMemset(M0, 0, ps * 5 * np * 4);
+    hipMemset(R, 0, ps * 10 * np * 4);
+    const dim3 grid((W + 16 + TW - 1) / TW, (H + TH - 1) / TH, np);
+    const double px = (double)W * H * np;
+    const char* names[3] = {"refreshing launch: windows + R0 + R1 + M out (80 B/px)", "last launch: windows + flow out (28 B/px)",
+                            "refresh traffic alone: R0 + R1 + M out (60 B/px)"};
+    const double bpp[3] = {80, 28, 60};
+    for (int rep = 0; rep < 2; rep++) {
+        double us[3];
+        us[0] = time_us([&] { hipLaunchKernelGGL(k<0>, grid, dim3(256), 0, 0, M0, R, M1, fl, ps); }, 10);
+        us[1] = time_us([&] { hipLaunchKernelGGL(k<1>, grid, dim3(256), 0, 0, M0, R, M1, fl, ps); }, 10);
+        us[2] = time_us([&] { hipLaunchKernelGGL(k<2>, grid, dim3(256), 0, 0, M0, R, M1, fl, ps); }, 10);
+        for (int i = 0; i < 3; i++)
+            printf("%-58s %8.1f us per 64 pairs  %6.2f us/pair  %5.2f TB/s = %.3f of 8 TB/s\n", names[i], us[i], us[i] / np,
+                   bpp[i] * px / us[i] / 1e6, bpp[i] * px / us[i] / 1e6 / 8.0);
+    }
+    run_win<1, 8>("b32, 8-row tiles (as built)", M0, fl, ps, np);
+    run_win<2, 8>("b64, 8-row tiles", M0, fl, ps, np);
+    run_win<4, 8>("b128, 8-row tiles", M0, fl, ps, np);
+    run_win<1, 16>("b32, 16-row tiles", M0, fl, ps, np);
+    run_win<2, 16>("b64, 16-row tiles", M0, fl, ps, np);
+    run_win<1, 32>("b32, 32-row tiles", M0, fl, ps, np);
+    return 0;
+}
