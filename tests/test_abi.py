@@ -119,3 +119,19 @@ int main(void)
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
     assert r.stdout.splitlines()[0] == "30 20736 Don't match image size"
+
+
+def test_microbenchmarks_compile_for_gfx950(tmp_path):
+    """The measurement micro-benchmarks under tools/ubench (profiles/r03_memory_shape_roofs.md and DESIGN.md §5-6 quote
+    them) still build for the target: hipcc cross-compiles without a GPU."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    ub = os.path.join(ROOT, "tools", "ubench")
+    for fn in sorted(os.listdir(ub)):
+        if fn.endswith(".hip"):
+            r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-w", "-c", os.path.join(ub, fn), "-o",
+                                str(tmp_path / (fn + ".o"))], capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, (fn, r.stderr[-1500:])
