@@ -247,6 +247,24 @@ def test_cli_contract_without_gpu():
 
 
 @needs_node
+def test_progress_prints_behind_tw_log():
+    """The reference prints `request:` / `consume:` / `finish optical flow:` / `finish consumer<i>` on stdout
+    (src/manager.cpp:74, src/consumer.cpp:49,55,92) — its own CLI had to dup2 stdout away to hide them.  Here they are
+    off by default, TW_LOG=1 puts them where the reference does, TW_LOG=2 on stderr (stdout stays pure JSON)."""
+    cmd = ["node", "commandline.js", "/nonexistent/a.png", "/nonexistent/b.png"]
+    quiet = subprocess.run(cmd, cwd=HOST, capture_output=True, text=True, timeout=60)
+    assert "request:" not in quiet.stdout + quiet.stderr
+    r = subprocess.run(cmd, cwd=HOST, capture_output=True, text=True, timeout=60, env=dict(os.environ, TW_LOG="2"))
+    assert r.returncode == 0 and r.stdout == quiet.stdout
+    lines = r.stderr.splitlines()
+    assert lines[0] == "request: /nonexistent/a.png <-> /nonexistent/b.png"
+    assert "consume: /nonexistent/a.png <-> /nonexistent/b.png" in lines
+    assert any(l.startswith("finish optical flow: ") for l in lines) and "finish consumer0" in lines
+    r = subprocess.run(cmd, cwd=HOST, capture_output=True, text=True, timeout=60, env=dict(os.environ, TW_LOG="1"))
+    assert "request: /nonexistent/a.png <-> /nonexistent/b.png" in r.stdout
+
+
+@needs_node
 @pytest.mark.gpu
 def test_cli_on_the_golden_pair():
     """BASELINE config[0] shape: one pair through the CLI with explicit options -> the 24 golden vectors."""
