@@ -635,6 +635,26 @@ def test_every_kernel_variant_behind_a_switch_is_bit_exact(twflow, oracle, env, 
         assert got == [want, want, want]
 
 
+@pytest.mark.parametrize("variant", ["41", "8", "256", "255", "254", "258", "259"])
+def test_51_tap_window_kernel_variants_are_bit_exact(twflow, oracle, variant, monkeypatch):
+    """winSize 50 (BASELINE config 5).  The product library runs wide levels with two 8-row sub-tiles per workgroup
+    sharing one 66-row register window (tw_blur_solve4y<25,...>, round 3: -7 %); the one-sub-tile kernel it replaced
+    (41), the packed-f32 kernel (8) and round 3's shorter-tile trials live in the variants library.  All the same bits."""
+    monkeypatch.setenv("TW_BLUR_VARIANT", variant)
+    kw = dict(pyrLevels=2, winSize=50, pyrIterations=2)
+    rng = np.random.default_rng(int(variant))
+    a = rand_img(rng, 203, 1003)
+    b = np.roll(a, 3, axis=1)
+    wx, wy = oracle.farneback(a, b, oracle.default_params(**kw))
+    with twflow.use_variants_library(), twflow.Engine(0, twflow.default_params(**kw), slots=2) as e:
+        gx, gy, _ = e.calculate_internal(a, b)
+        tk = [e.submit(a, b, 10, 1.0) for _ in range(2)]
+        got = [e.wait(t)["vector"] for t in tk]
+    assert_same(gx, wx, "flowx winSize 50 variant %s" % variant)
+    assert_same(gy, wy, "flowy winSize 50 variant %s" % variant)
+    assert got == [oracle.span_scan(wx, wy, 10, 1.0)] * 2
+
+
 @pytest.mark.parametrize("env", [dict(TW_BLUR_VARIANT="60"), dict(TW_POLY_VARIANT="0"), dict(TW_BLUR_SMALL="3"),
                                  dict(TW_UPD_NY="1")])
 def test_product_library_refuses_the_ab_kernel_switches(twflow, env, monkeypatch):

@@ -1029,9 +1029,12 @@ void launch_blur(tw_engine* e, hipStream_t st, int w, int h, int ld, long long p
         if (wide && e->blur_variant == 255) { hipLaunchKernelGGL((tw_blur_solve4<25, 256, 32, 5, true, 2, 2, 2, true, false>), dim3((w + 191) / 192, (h + 4) / 5, npairs), dim3(256), 0, st, a); return; }
         if (wide && e->blur_variant == 254) { hipLaunchKernelGGL((tw_blur_solve4<25, 256, 32, 4, true, 2, 2, 2, true, false>), dim3((w + 191) / 192, (h + 3) / 4, npairs), dim3(256), 0, st, a); return; }
         if (wide && e->blur_variant == 258) { hipLaunchKernelGGL((tw_blur_solve4<25, 256, 32, 8, true, 2, 2, 2, true, false>), dim3((w + 191) / 192, gy, npairs), dim3(256), 0, st, a); return; }
+        if (wide && e->blur_variant == 41) { hipLaunchKernelGGL((tw_blur_solve4<25, 256, 32, 8, true, 2, 2, 2, false, false>), dim3((w + 191) / 192, gy, npairs), dim3(256), 0, st, a); return; }
         if (wide && e->blur_variant == 259) { hipLaunchKernelGGL((tw_blur_solve4<25, 256, 32, 5, true, 2, 2, 2, false, false>), dim3((w + 191) / 192, (h + 4) / 5, npairs), dim3(256), 0, st, a); return; }
 #endif
-        if (wide) hipLaunchKernelGGL((tw_blur_solve4<25, 256, 32, 8, true, 2, 2, 2, false, false>), dim3((w + 191) / 192, gy, npairs), dim3(256), 0, st, a);
+        // wide levels: two vertically adjacent 8-row sub-tiles share one 66-row register window (round 3: -7 % against the
+        // one-sub-tile kernel with its 58-row window per 8 rows, which TW_BLUR_VARIANT=41 of the variants library selects)
+        if (wide) hipLaunchKernelGGL((tw_blur_solve4y<25, 256, 32, 8, 2>), dim3((w + 191) / 192, (h + 15) / 16, npairs), dim3(256), 0, st, a);
         else hipLaunchKernelGGL((tw_blur_solve8<25, 128, 32, 8, true, false>), dim3((w + 63) / 64, gy, npairs), dim3(128), 0, st, a);
     } else {
         // any other window size: generic kernel (same arithmetic, runtime loops)

@@ -2180,7 +2180,9 @@ __global__ __launch_bounds__(5 * COLS) void tw_blur_solve_pp(BlurArgs a)
     }
 }
 
-#ifdef TW_VARIANTS  // A/B kernel (TW_BLUR_VARIANT=2, measured equal within the noise): VARIANTS=1 builds only
+// (round 3: ships for the 51-tap window of winSize 50 — 58 window rows per 8 output rows become 66 per 16, -7 % on the
+//  launch, config 5 0.367 -> 0.385 of its roofline; the 31-tap instantiation stays an A/B kernel of the variants library,
+//  TW_BLUR_VARIANT=2: equal within the noise there)
 // -----------------------------------------------------------------------------------------------------
 // tw_blur_solve4y<MH,COLS,HALO,TH,NSUB> : tw_blur_solve4 with NSUB vertically adjacent TH-row sub-tiles per workgroup.
 //   The vertical pass runs once over a TH*NSUB + 2*MH row register window (the window rows of adjacent sub-tiles
@@ -2350,8 +2352,6 @@ __global__ __launch_bounds__(COLS) __attribute__((amdgpu_waves_per_eu(4, 8))) vo
         subtile(std::true_type{}, y00 + TH);
     }
 }
-
-#endif  // TW_VARIANTS
 
 // -----------------------------------------------------------------------------------------------------
 // tw_blur_solve8<MH,COLS,HALO,TH,FUSED,PREFETCH> : v4's tiling and occupancy (COLS threads, 40 KB LDS, 4
