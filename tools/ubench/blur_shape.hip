@@ -74,6 +74,40 @@ __global__ __launch_bounds__(256) void k(const float* __restrict__ Min, const fl
         }
     }
 }
+// the refresh's traffic alone in another lane shape: every lane owns TWO horizontally adjacent pixels (8-byte loads of
+// R0 and of the R1 rows, 8-byte M stores): half the vector-memory instructions for the same bytes
+__global__ __launch_bounds__(256) void krefresh2(const float* __restrict__ R, float* __restrict__ Mout, long long ps)
+{
+    typedef float __attribute__((ext_vector_type(2))) f2;
+    int bx, by, z;
+    xcd_remap(bx, by, z);
+    const int x0 = bx * TW - 16, y0 = by * TH, tid = threadIdx.x;
+    const float* R0 = R + (long long)(2 * z) * 5 * ps;
+    const float* R1 = R0 + 5 * ps;
+    float* Mo = Mout + (long long)z * 5 * ps;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {  // 112 pixel pairs x 8 rows = 896 items over 256 lanes
+        const int p = tid + i * 256;
+        if (p >= 112 * TH) break;
+        const int r = p / 112, cp = p - r * 112;
+        const int x = x0 + 2 * cp, y = y0 + r;
+        const bool valid = x >= 0 && x + 1 < W && y < H;
+        const int xc = min(max(x, 0), W - 4) & ~1, yc = min(y, H - 2);
+        const long long o = (long long)yc * LD + xc;
+        f2 s = {0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 5; c++) {
+            s += *(const f2*)(R0 + o + c * ps);
+            const f2 a = *(const f2*)(R1 + o + c * ps), b = *(const f2*)(R1 + o + c * ps + 2);
+            const f2 d = *(const f2*)(R1 + o + c * ps + LD), e = *(const f2*)(R1 + o + c * ps + LD + 2);
+            s += a + b + d + e;
+        }
+        if (valid) {
+#pragma unroll
+            for (int c = 0; c < 5; c++) *(f2*)(Mo + o + c * ps) = s + (float)c;
+        }
+    }
+}
 // window loads only, in other shapes: VEC floats per lane and load (b32 / b64 / b128: a wave then covers 64 * VEC columns),
 // ROWS output rows per tile (window = ROWS + 30 rows).  Same bytes per output row for a given ROWS.
 template <int VEC, int ROWS>
@@ -171,6 +205,11 @@ int main()
         for (int i = 0; i < 3; i++)
             printf("%-58s %8.1f us per 64 pairs  %6.2f us/pair  %5.2f TB/s = %.3f of 8 TB/s\n", names[i], us[i], us[i] / np,
                    bpp[i] * px / us[i] / 1e6, bpp[i] * px / us[i] / 1e6 / 8.0);
+    }
+    {
+        const double u = time_us([&] { hipLaunchKernelGGL(krefresh2, grid, dim3(256), 0, 0, R, M1, ps); }, 10);
+        printf("%-58s %8.1f us per 64 pairs  %6.2f us/pair  %5.2f TB/s\n", "refresh traffic alone, 2 pixels per lane (8-byte accesses)", u,
+               u / np, 60.0 * px / u / 1e6);
     }
     run_win<1, 8>("b32, 8-row tiles (as built)", M0, fl, ps, np);
     run_win<2, 8>("b64, 8-row tiles", M0, fl, ps, np);
