@@ -472,9 +472,19 @@ def main():
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%s: launch one rank per GPU (torch.distributed.run "
                          "--nproc-per-node %d), or run without torchrun" % (args.gpus, os.environ["WORLD_SIZE"], args.gpus))
     rank = int(os.environ.get("RANK", "0"))
-    if not os.path.exists(os.path.join(ROOT, "tidal-wave_amd", "libtwflow.so")) and int(os.environ.get("LOCAL_RANK", "0")) == 0:
-        import __graft_entry__  # fresh checkout: the binaries are git-ignored (building is not a fallback)
-        __graft_entry__.build()
+    so = os.path.join(ROOT, "tidal-wave_amd", "libtwflow.so")
+    if not os.path.exists(so):
+        # fresh checkout: the binaries are git-ignored (building is not a fallback).  Local rank 0 builds, the other
+        # ranks wait for the library to appear (they have no process group yet to wait in).
+        if int(os.environ.get("LOCAL_RANK", "0")) == 0:
+            import __graft_entry__
+            __graft_entry__.build()
+        else:
+            t_wait = time.time()
+            while not os.path.exists(QUEUE_BIN) and time.time() - t_wait < 900:  # the last artefact build() makes
+                time.sleep(1.0)
+            if not os.path.exists(so):
+                raise SystemExit("bench.py: libtwflow.so did not appear (is local rank 0 building it?)")
     if args.mode == "queue":
         # one process drives every device: under a launcher rank 0 does, the other ranks stay off the GPUs
         if rank == 0:
