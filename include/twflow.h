@@ -28,7 +28,9 @@
 extern "C" {
 #endif
 
-#define TWFLOW_ABI_VERSION 1
+/* 2 (round 3): + tw_device_pci_bus_id, tw_host_register / tw_host_unregister, tw_has_variants, TW_OPT_POLYEXP_F32.
+ * Purely additive: a consumer built against version 1 runs unchanged. */
+#define TWFLOW_ABI_VERSION 2
 
 /* Status codes.  The first four are enum ErrorCode of /root/reference/src/opticalflow.h:9-14. */
 typedef enum tw_status {
