@@ -134,7 +134,16 @@ def cpu_baseline(pairs, njobs=0):
         t.join()
     dt = time.perf_counter() - t0
     host_cores = os.cpu_count() or cores
-    return {"value": round(njobs / dt, 3), "unit": "pairs/s", "cores": threads, "kind": "port",
+    model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.lower().startswith("model name"):
+                    model = ln.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {"value": round(njobs / dt, 3), "unit": "pairs/s", "cores": threads, "kind": "port", "cpu_model": model,
             "single_thread_pairs_per_s": round(1.0 / one, 3),
             "host_cores": host_cores,
             "extrapolated_all_host_cores_pairs_per_s": round(njobs / dt / threads * host_cores, 1),
