@@ -4,17 +4,23 @@
 Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 it is launched through
 torch.distributed.run, one rank per GPU.
 
-Two workloads, chosen EXPLICITLY with --mode and named in config.workload / config.mode (a 1 -> N curve is always
+Three workloads, chosen EXPLICITLY with --mode and named in config.workload / config.mode (a 1 -> N curve is always
 one workload; VERDICT r2: `--gpus N` used to switch workloads silently between N = 1 and N > 1):
 
-  --mode resident (default; what the driver runs at every N)
-      One "step" = one pass of the hot path over one batch of BATCH synthetic 1920x1080 pairs per GPU that are already
-      resident in HBM when the timed region starts; inside the timed region engine batch s+1 is submitted before the
-      results of batch s are collected (a service's steady state: the engine keeps up to three batches outstanding),
-      all K steps complete inside the region.  Pairs shard embarrassingly across ranks (weak scaling: every rank
-      processes its own batches); there is no data-path collective — torch.distributed (RCCL) is used only for the
-      barrier and the max-over-ranks of the elapsed time.  Without torchrun, `--gpus N` (N > 1) starts the N ranks
-      itself (a torch.distributed.run child process) — the same workload, never another one.
+  --mode pinned (default; what the driver runs at every N — BASELINE.json configs[2]'s shape)
+      One "step" = one pass of the hot path over BATCH (256) synthetic 1920x1080 pairs per GPU that sit in page-locked
+      HOST memory (a ring of BATCH distinct buffers: no upload re-reads a host page inside a step): the pairs go up on
+      the engine's copy stream in 128-pair engine batches INSIDE the timed region (the upload of batch s+1 runs under
+      the kernels of batch s), only the hit records come back (reference: upload and download are part of the GPU call,
+      src/opticalflow.cpp:100,115-116).  Engine batch s+1 is submitted before the results of batch s are collected (a
+      service's steady state: the engine keeps up to three batches outstanding), all K steps complete inside the
+      region.  Pairs shard embarrassingly across ranks (weak scaling: every rank processes its own batches); there is
+      no data-path collective — torch.distributed (RCCL) is used only for the barrier and the max-over-ranks of the
+      elapsed time.  Without torchrun, `--gpus N` (N > 1) starts the N ranks itself (a torch.distributed.run child
+      process) — the same workload, never another one.
+  --mode resident
+      The same steps with the pairs already resident in HBM when the timed region starts (rounds 1-3's headline; at
+      N = 1 the pinned line carries it as the extra `resident_hbm`).
   --mode queue
       BASELINE.json configs[3]'s shape: BATCH x N in-memory page-locked 1080p pairs through ONE twhost::Manager queue
       with one consumer per GPU (tools/bench_queue.cpp; reference src/manager.cpp:55-59,68-78); uploads are inside the
@@ -30,10 +36,11 @@ Every line — both modes, every N — carries
   cpu_baseline  the CPU oracle (a scalar port of OpenCV 2.4.9's algorithm; OpenCV itself is not installable here)
                 timed on this box's host cores on a bounded sample, by rank 0, outside the timed region (it does not
                 depend on N)
-At N = 1 in resident mode the line also carries, all measured outside the timed region and never `value`:
-  config3_host_pinned   BASELINE configs[2]: 2048 x 1080p pairs from page-locked HOST buffers in 128-pair engine
-                batches, uploads on the copy stream under the previous batch's kernels — pipeline fill and steady
-                state reported separately
+At N = 1 in pinned / resident mode the line also carries, all measured outside the timed region and never `value`:
+  resident_hbm  (pinned mode) the same steps from HBM-resident pairs, with that run's own level-0 blur roofline
+  input_sensitivity   VERDICT r3 #4: pairs/s of the same steps when ALL pairs are warped (|v| <= 6 px), warped by up to
+                48 px, or identical — what the flow-dependent R1 gather costs
+  config3_host_pinned   the headline's shape over 2048 pairs with pipeline fill and steady state reported separately
   config5_4k    BASELINE configs[4] on one GPU (3840x2160, pyrLevels 5, winSize 50, iters 5): 64 pairs of 4 distinct
                 images, with `roofline_cfg5` for its 51-tap window kernel from in-run events
   queue_sharded the queue workload on one GPU (2048 pairs)
@@ -73,8 +80,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--mode", choices=("resident", "queue"), default="resident",
-                    help="resident: pairs resident in HBM, one rank per GPU (the driver's workload); queue: in-memory "
+    ap.add_argument("--mode", choices=("pinned", "resident", "queue"), default="pinned",
+                    help="pinned: pairs in page-locked host memory, uploads inside the timed region, one rank per GPU "
+                         "(the driver's workload, BASELINE configs[2]); resident: pairs resident in HBM; queue: in-memory "
                          "host pairs through one manager queue with one consumer per GPU, uploads timed")
     ap.add_argument("--batch", type=int, default=256, help="1080p pairs per step per GPU (2 engine batches)")
     ap.add_argument("--slots", type=int, default=128, help="pairs per engine batch (level-major schedule, one launch "
@@ -489,8 +497,11 @@ def main():
             import __graft_entry__
             __graft_entry__.build()
         else:
+            # build() writes tidal-wave_amd/.build_done LAST, whatever it built (waiting for bench_queue hung on
+            # a box without node headers, and a stale bench_queue ended the wait at once)
+            stamp = os.path.join(ROOT, "tidal-wave_amd", ".build_done")
             t_wait = time.time()
-            while not os.path.exists(QUEUE_BIN) and time.time() - t_wait < 900:  # the last artefact build() makes
+            while not (os.path.exists(stamp) and os.path.exists(so)) and time.time() - t_wait < 900:
                 time.sleep(1.0)
             if not os.path.exists(so):
                 raise SystemExit("bench.py: libtwflow.so did not appear (is local rank 0 building it?)")
@@ -537,6 +548,24 @@ def main():
     # synthetic pairs: the same seeds on every rank (weak scaling: each rank owns its batch)
     host_pairs = [synth.make_pair(i, H, W) for i in range(args.distinct)]
     dev_pairs = [(eng.upload(a), eng.upload(b)) for a, b in host_pairs]
+    pinned_mode = args.mode == "pinned"
+    import ctypes
+
+    def make_ring(pairs, n=None):
+        """`n` (default: one step's) DISTINCT page-locked pair buffers filled by cycling `pairs`: inside a step no upload
+        re-reads a host page.  Returns the raw pointers tw_submit_u8 takes."""
+        n = n or args.batch
+        big = eng.host_array((n, 2, H, W))
+        u8p = ctypes.POINTER(ctypes.c_uint8)
+        ptrs = []
+        for j in range(n):
+            a, b = pairs[j % len(pairs)]
+            big[j, 0][:] = a
+            big[j, 1][:] = b
+            ptrs.append((big[j, 0].ctypes.data_as(u8p), big[j, 1].ctypes.data_as(u8p)))
+        return big, ptrs
+
+    ring = make_ring(host_pairs) if pinned_mode else None
 
     def barrier():
         torch.cuda.synchronize()
@@ -545,13 +574,23 @@ def main():
         torch.cuda.synchronize()
 
     flagged = [0]
+    cursor = [0]
+    source = {"pinned": pinned_mode, "ring": ring, "dev": dev_pairs}
 
     def submit_engine_batch(n):
         # one engine batch (the engine launches every `slots` pairs, level-major)
         tickets = []
-        for j in range(n):
-            da, db = dev_pairs[j % len(dev_pairs)]
-            tickets.append(eng.submit_dev(da, db, W, H, W, SPAN, THRESHOLD))
+        if source["pinned"]:
+            ptrs = source["ring"][1]
+            for j in range(n):
+                pa, pb = ptrs[(cursor[0] + j) % len(ptrs)]
+                tickets.append(eng.submit_ptr(pa, pb, W, H, W, SPAN, THRESHOLD))
+        else:
+            dev = source["dev"]
+            for j in range(n):
+                da, db = dev[(cursor[0] + j) % len(dev)]
+                tickets.append(eng.submit_dev(da, db, W, H, W, SPAN, THRESHOLD))
+        cursor[0] += n
         return tickets
 
     def collect(tickets):
@@ -578,6 +617,15 @@ def main():
 
     def run_steps(k):
         run_pairs(args.batch * k)  # K steps back to back: no drain between steps
+
+    def timed_rate(k):
+        """pairs/s of k steps of the current source, outside the headline's timed region (extras)."""
+        step()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        run_steps(k)
+        torch.cuda.synchronize()
+        return args.batch * k / (time.perf_counter() - t)
 
     # single-pair latency (configs[1]) and a result check before timing
     res0 = eng.diff(host_pairs[0][0], host_pairs[0][1], SPAN, THRESHOLD)
@@ -639,6 +687,41 @@ def main():
         fused_same = (flagged[0] - before) == per_step * (nf + 1)
         eng.set_option(twflow.OPT_SCAN_FUSED_FINAL, 0)
 
+    # the same steps from HBM-resident pairs (rounds 1-3's headline), with that run's own level-0 blur roofline
+    resident_extra = None
+    sensitivity = None
+    if world == 1 and not args.no_extras:
+        nf = max(2, args.steps // 2)
+        if pinned_mode:
+            source["pinned"] = False
+            if not args.no_prof:
+                eng.prof_select(twflow.K_BLUR_SOLVE, 0)
+            r_rate = timed_rate(nf)
+            r_prof = eng.prof_read(twflow.K_BLUR_SOLVE) if not args.no_prof else (0.0, 0)
+            eng.prof_select(-1, -2)
+            source["pinned"] = True
+            resident_extra = {"pairs_per_s": round(r_rate, 2), "steps": nf, "blur_ms_launches": r_prof}
+        # what the synthetic mix is worth — the flow-dependent R1 gather's locality follows the flow field
+        sensitivity = {}
+        base_dev = source["dev"]
+        was_pinned = source["pinned"]
+        source["pinned"] = False
+        for key, mk in (("all_warped_6px", lambda i: synth.make_pair(i, H, W, kind=0)),
+                        ("all_warped_48px", lambda i: synth.make_pair(i, H, W, kind=0, amp=8.0)),
+                        ("all_identical", lambda i: synth.make_pair(i, H, W, kind=3))):
+            pairs_k = [mk(i) for i in range(args.distinct)]
+            source["dev"] = [(eng.upload(a), eng.upload(b)) for a, b in pairs_k]
+            sensitivity[key] = round(timed_rate(nf), 2)
+        source["dev"] = base_dev
+        sensitivity["mix_50_25_25_resident"] = round(timed_rate(nf), 2)
+        source["pinned"] = was_pinned
+        vals = [sensitivity[k] for k in ("all_warped_6px", "all_warped_48px", "all_identical", "mix_50_25_25_resident")]
+        sensitivity["spread_pct"] = round((max(vals) - min(vals)) / sensitivity["mix_50_25_25_resident"] * 100, 2)
+        sensitivity["note"] = ("pairs/s of %d steps from HBM-resident pairs, outside the timed region, same engine: all %d "
+                               "distinct pairs warped by a smooth flow of |v| <= 6 px per component (SURVEY 8d's warp), by "
+                               "|v| <= 48 px, all identical, and the headline's 50/25/25 mix (warped / painted rectangle / "
+                               "identical)" % (nf, args.distinct))
+
     if rank == 0:
         value = pairs_total / elapsed
         bytes_pair = eng.algorithmic_bytes_pair(W, H, SPAN)
@@ -682,9 +765,17 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "resident: batch of %d x 1920x1080 u8 gray pairs per GPU per step, resident in HBM, "
-                                   "%s" % (args.batch, PARAMS_TEXT),
-                       "mode": "resident", "batch_per_gpu": args.batch, "engine_batch": args.slots,
+            "config": {"workload": ("pinned: %d x 1920x1080 u8 gray pairs per GPU per step in page-locked HOST memory (a "
+                                    "ring of %d distinct buffers), uploaded on the copy stream in %d-pair engine batches "
+                                    "INSIDE the timed region under the previous batch's kernels, hit records back "
+                                    "(BASELINE configs[2]), %s" % (args.batch, args.batch, args.slots, PARAMS_TEXT))
+                       if pinned_mode else
+                       ("resident: batch of %d x 1920x1080 u8 gray pairs per GPU per step, resident in HBM, "
+                        "%s" % (args.batch, PARAMS_TEXT)),
+                       "mode": args.mode, "batch_per_gpu": args.batch, "engine_batch": args.slots,
+                       "h2d_MB_per_pair": round(2 * W * H / 1e6, 2) if pinned_mode else 0.0,
+                       "synthetic_mix": "%d distinct pairs cycled: 50 %% warped (|v| <= 6 px), 25 %% painted rectangle, "
+                                        "25 %% identical (SURVEY 8d); see input_sensitivity" % args.distinct,
                        "parallelism": "pairs sharded over %d GPU(s), one rank per GPU, no collective" % world,
                        "numa_node_rank0": numa_node, "backend": backend if world > 1 else None,
                        "rehearsal": None if ndev >= world else "%d ranks time-share %d device(s): a rehearsal of the "
@@ -709,7 +800,18 @@ def main():
             "roofline": roof(twflow.K_BLUR_SOLVE),
             "roofline_polyexp": roof(twflow.K_POLYEXP),
             "flagged_vectors": flagged_total,
+            "input_sensitivity": sensitivity,
         }
+        if resident_extra is not None:
+            ms_r, n_r = resident_extra.pop("blur_ms_launches")
+            pairs_r = args.batch * (resident_extra["steps"] + 1)
+            resident_extra["roofline"] = roofline_obj(
+                twflow.KERNEL_NAMES[twflow.K_BLUR_SOLVE], ms_r, n_r,
+                eng.algorithmic_bytes(twflow.K_BLUR_SOLVE, 0, W, H) * 3 * pairs_r, 3 * pairs_r / max(n_r, 1), traffic,
+                chunk=eng.level_chunk(W, H, 0)) if n_r else None
+            resident_extra["note"] = ("the headline's steps with the pairs already resident in HBM (no uploads): rounds "
+                                      "1-3's `value`; outside the timed region")
+            line["resident_hbm"] = resident_extra
         extras = world == 1 and not args.no_extras
         if extras:
             # the other BASELINE configs, outside the timed region (never `value`)

@@ -151,7 +151,11 @@ tw_status tw_set_option(tw_engine* e, int option, int value);
  * soon as tw_submit_u8 returns (memory page-locked behind the library's back, e.g. by a direct hipHostRegister, is
  * staged too — correct, one memcpy slower).  The blocks are usable by the engines of every device and by every
  * thread (the table of them is process-wide).  Either way the upload of batch j+1 overlaps the kernels of batch j
- * (BASELINE config 3: "pinned H2D/D2H overlapped on a side stream"). */
+ * (BASELINE config 3: "pinned H2D/D2H overlapped on a side stream").
+ * Releasing a block: tw_host_free / tw_host_unregister wait only for the uploads of the engine they are called on.
+ * The caller must have collected (tw_wait) every ticket of EVERY engine that was handed images from the block before
+ * it releases it.  A block is released the way it was made: tw_host_free on a registered block, or
+ * tw_host_unregister on a tw_host_alloc block, answers TW_E_BAD_PARAMETER and releases nothing. */
 tw_status tw_host_alloc(tw_engine* e, size_t bytes, void** hptr);
 tw_status tw_host_free(tw_engine* e, void* hptr);
 /* Page-lock / release memory the caller owns (hipHostRegister / hipHostUnregister + the table above). */

@@ -532,6 +532,13 @@ def test_page_lock_table_is_process_wide_and_never_stale(twflow, oracle):
         assert L.tw_host_register(e1._h, C.c_void_p(buf.ctypes.data), buf.nbytes) == twflow.TW_OK
         assert e1.wait(e1.submit(buf[0], buf[1], 10, 1.0))["vector"] == want
         assert e2.wait(e2.submit(buf[0], buf[1], 10, 1.0))["vector"] == want
+        # a block is released the way it was made: tw_host_free on a registered block must not reach
+        # hipHostFree on the caller's memory, and it must leave the block registered
+        assert L.tw_host_free(e2._h, C.c_void_p(buf.ctypes.data)) == twflow.TW_E_BAD_PARAMETER
+        assert b"tw_host_unregister" in L.tw_last_error(e2._h)
+        keep = e1.host_array((16,))
+        assert L.tw_host_unregister(e2._h, C.c_void_p(keep.ctypes.data)) == twflow.TW_E_BAD_PARAMETER
+        assert e1.wait(e1.submit(buf[0], buf[1], 10, 1.0))["vector"] == want   # still registered, still usable
         assert L.tw_host_unregister(e2._h, C.c_void_p(buf.ctypes.data)) == twflow.TW_OK
         assert L.tw_host_unregister(e2._h, C.c_void_p(buf.ctypes.data)) == twflow.TW_E_BAD_PARAMETER
         buf[0, 5:9, 5:9] = 0  # pageable now: may change right after submit returns (staged)

@@ -144,6 +144,55 @@ def test_consumers_are_placed_on_their_gpus_numa_node(tmp_path):
     assert all(c["numa_node"] == -1 and c["cpus"] == allowed for c in out["consumers"])
 
 
+def test_queue_driver_json_with_eight_devices_on_two_nodes(tmp_path):
+    """what `bench.py --mode queue --gpus 8` parses, before an 8-GPU node exists — tools/bench_queue.cpp
+    itself on the stub backend with 8 pretend devices on 2 pretend NUMA nodes: one consumer per device, every consumer
+    warm, placed on its device's node, pairs sum to the request, and every consumer's idle time inside the timed
+    region is in the line (a starved consumer at N = 8 must be visible)."""
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    r = subprocess.run(["make", "-s", "-C", HOST, "queue_stub"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    devs = [("0000:%02x:00.0" % (0x05 + 0x10 * i), 0 if i < 4 else 1) for i in range(8)]
+    sysroot = tmp_path / "sys"
+    nodes = _fake_sysfs(str(sysroot), devs)
+    pg = tmp_path / "pgm"
+    pg.mkdir()
+    rng = np.random.default_rng(3)
+    for i in range(2):
+        a = rng.integers(0, 256, (48, 64), dtype=np.uint8)
+        b = a.copy()
+        if i == 0:
+            b[0, 0] ^= 0xFF  # the stub answers one canned vector when the first bytes differ
+        for q, im in (("a", a), ("b", b)):
+            with open(pg / ("pair_%d_%s.pgm" % (i, q)), "wb") as f:
+                f.write(b"P5\n64 48\n255\n" + im.tobytes())
+    env = dict(os.environ, TW_SYSFS_ROOT=str(sysroot), TW_STUB_DEVICES="8", TW_STUB_PCI=",".join(b for b, _ in devs))
+    env.pop("TW_NUMA", None)
+    env.pop("TW_CONSUMERS_PER_DEVICE", None)
+    r = subprocess.run([os.path.join(HOST, "build", "bench_queue_stub"), "--pgm-dir", str(pg), "--pairs", "4096",
+                        "--devices", "8", "--batch", "32", "--warmup-batches", "1"], capture_output=True, text=True,
+                       timeout=300, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["devices"] == 8 and out["consumers"] == 8 and out["pairs"] == 4096 and out["errors"] == 0
+    assert out["all_consumers_warm"] is True and out["report"]["data"] >= 4096
+    assert out["flagged_vectors"] == 2048  # pair 0 of the two cycled pairs differs
+    pc = out["per_consumer"]
+    assert sorted(c["device"] for c in pc) == list(range(8))
+    assert sum(c["pairs"] for c in pc) == 4096
+    two_nodes = len(os.sched_getaffinity(0)) >= 2
+    for c in pc:
+        bus, node = devs[c["device"]]
+        assert c["pci"] == bus
+        if two_nodes:
+            assert c["numa_node"] == node and c["cpus"] == len(nodes[node]), c
+        for k in ("idle_ms", "idle_frac", "wait_ms", "first_job_ms"):
+            assert k in c, k
+        assert 0.0 <= c["idle_frac"] <= 1.0 and c["idle_ms"] <= out["seconds"] * 1e3 + 1e-6
+        assert c["pairs"] > 0, "consumer %d of 8 got nothing from a 4096-pair queue" % c["id"]
+
+
 @pytest.mark.gpu
 def test_c99_consumer_device_branch(tmp_path):
     """tests/test_abi.py::test_header_is_plain_c_and_links on a GPU box: the C99 consumer's tw_diff_u8 call runs

@@ -354,3 +354,78 @@ def test_bmp_and_pnm_files(lib, tmp_path):
     assert _load(lib, tmp_path / "big.pgm") is None
     (tmp_path / "trunc.ppm").write_bytes(b"P6 10 10 255\n" + bytes(100))
     assert _load(lib, tmp_path / "trunc.ppm") is None
+
+
+def _png_chunk(tag, data):
+    return len(data).to_bytes(4, "big") + tag + data + (zlib.crc32(tag + data) & 0xFFFFFFFF).to_bytes(4, "big")
+
+
+def test_png_chunk_rules_of_libpng_and_header_bounds(lib, tmp_path):
+    """ADVICE r3: cv::imread (libpng) refuses a PNG whose IHDR / PLTE / IDAT chunk has a bad CRC, whose first chunk is
+    not IHDR or whose IDATs are not consecutive — the job then answers "Can't open" (src/opticalflow.cpp:38-41).  A bad
+    CRC in an ANCILLARY chunk is only a warning there.  And no decoder may allocate the image a header announces before
+    the payload can hold it; a failed decode reports no size (it used to size the consumer's page-locked arena)."""
+    import resource
+    from PIL import Image
+    rng = np.random.default_rng(5)
+    g = rng.integers(0, 256, (40, 64), dtype=np.uint8)
+    raw = b"".join(b"\0" + g[y].tobytes() for y in range(40))
+    z = zlib.compress(raw, 6)
+    sig = b"\x89PNG\r\n\x1a\n"
+    ihdr = (64).to_bytes(4, "big") + (40).to_bytes(4, "big") + bytes([8, 0, 0, 0, 0])
+    good = sig + _png_chunk(b"IHDR", ihdr) + _png_chunk(b"tEXt", b"k\0v") + _png_chunk(b"IDAT", z[:50]) + \
+        _png_chunk(b"IDAT", z[50:]) + _png_chunk(b"IEND", b"")
+    (tmp_path / "good.png").write_bytes(good)
+    assert np.array_equal(_load(lib, tmp_path / "good.png"), g)
+    assert np.array_equal(np.asarray(Image.open(tmp_path / "good.png")), g)
+
+    def flip_crc(blob, tag):
+        i = blob.index(tag) - 4
+        n = int.from_bytes(blob[i:i + 4], "big")
+        b = bytearray(blob)
+        b[i + 8 + n + 3] ^= 1
+        return bytes(b)
+
+    for tag, refused in ((b"IHDR", True), (b"IDAT", True), (b"tEXt", False)):
+        (tmp_path / "crc.png").write_bytes(flip_crc(good, tag))
+        got = _load(lib, tmp_path / "crc.png")
+        assert (got is None) == refused, tag
+        if not refused:
+            assert np.array_equal(got, g)
+    # a palette whose CRC is wrong would silently change pixels
+    pal = bytes(rng.integers(0, 256, 48, dtype=np.uint8))
+    pi = rng.integers(0, 16, (8, 8), dtype=np.uint8)
+    praw = b"".join(b"\0" + pi[y].tobytes() for y in range(8))
+    pih = (8).to_bytes(4, "big") + (8).to_bytes(4, "big") + bytes([8, 3, 0, 0, 0])
+    pgood = sig + _png_chunk(b"IHDR", pih) + _png_chunk(b"PLTE", pal) + _png_chunk(b"IDAT", zlib.compress(praw)) + _png_chunk(b"IEND", b"")
+    (tmp_path / "pal.png").write_bytes(pgood)
+    assert _load(lib, tmp_path / "pal.png") is not None
+    (tmp_path / "palcrc.png").write_bytes(flip_crc(pgood, b"PLTE"))
+    assert _load(lib, tmp_path / "palcrc.png") is None
+    # chunk order: IHDR first, IDATs consecutive, PLTE before IDAT
+    (tmp_path / "o1.png").write_bytes(sig + _png_chunk(b"tEXt", b"k\0v") + _png_chunk(b"IHDR", ihdr) + _png_chunk(b"IDAT", z) + _png_chunk(b"IEND", b""))
+    assert _load(lib, tmp_path / "o1.png") is None
+    (tmp_path / "o2.png").write_bytes(sig + _png_chunk(b"IHDR", ihdr) + _png_chunk(b"IDAT", z[:50]) + _png_chunk(b"tEXt", b"k\0v") +
+                                      _png_chunk(b"IDAT", z[50:]) + _png_chunk(b"IEND", b""))
+    assert _load(lib, tmp_path / "o2.png") is None
+    (tmp_path / "o3.png").write_bytes(sig + _png_chunk(b"IHDR", pih) + _png_chunk(b"IDAT", zlib.compress(praw)) + _png_chunk(b"PLTE", pal) + _png_chunk(b"IEND", b""))
+    assert _load(lib, tmp_path / "o3.png") is None
+    # huge header, tiny body: refused without allocating the announced image (RLIMIT_AS would make a 1-8 GiB
+    # allocation fail loudly; the decoders must not even try) and without reporting its size
+    huge_ihdr = (32768).to_bytes(4, "big") + (32768).to_bytes(4, "big") + bytes([16, 6, 0, 0, 0])
+    (tmp_path / "huge.png").write_bytes(sig + _png_chunk(b"IHDR", huge_ihdr) + _png_chunk(b"IDAT", z) + _png_chunk(b"IEND", b""))
+    (tmp_path / "huge.pgm").write_bytes(b"P5 32768 32768 255\n" + bytes(20))
+    (tmp_path / "huge2.pgm").write_bytes(b"P2 32768 32768 255\n1 2 3\n")
+    (tmp_path / "huge.pbm").write_bytes(b"P1 32768 32768\n0 1\n")
+    soft, hard = resource.getrlimit(resource.RLIMIT_AS)
+    import psutil
+    vm = psutil.Process().memory_info().vms
+    resource.setrlimit(resource.RLIMIT_AS, (vm + (256 << 20), hard))
+    try:
+        for name in ("huge.png", "huge.pgm", "huge2.pgm", "huge.pbm"):
+            out = C.create_string_buffer(16)
+            w, h = C.c_int(-1), C.c_int(-1)
+            ok = lib.twt_load_gray(str(tmp_path / name).encode(), out, 16, C.byref(w), C.byref(h))
+            assert not ok and w.value == 0 and h.value == 0, (name, ok, w.value, h.value)
+    finally:
+        resource.setrlimit(resource.RLIMIT_AS, (soft, hard))

@@ -543,6 +543,17 @@ tw_status get_plan(tw_engine* e, int w0, int h0, Plan** out)
         long long target = 300000;
         if (const char* ev = getenv("TW_CHUNK_TILES")) target = std::max(1, atoi(ev));
         long long c = (target + tiles - 1) / tiles;
+        // TW_CHUNK_PAIRS_LEVELS="p0,p1,...": pairs per launch at level 0, 1, ... (0 / missing: the rule above) — the
+        // round-4 Infinity-Cache experiment (does a level's chain run faster when a chunk's R / M planes fit the 256 MB
+        // memory-side cache between its kernels?  profiles/r04_mall_chunks.md)
+        if (const char* ev = getenv("TW_CHUNK_PAIRS_LEVELS")) {
+            const char* q = ev;
+            for (int lv = 0; lv < k && q; lv++) {
+                q = strchr(q, ',');
+                if (q) q++;
+            }
+            if (q && atoi(q) > 0) c = atoi(q);
+        }
         L.chunk = (int)std::min<long long>(std::max<long long>(c, 1), e->cap);
     }
     for (int k = 0; k <= pl->levels; k++) {
@@ -1347,17 +1358,28 @@ tw_status check_dims(tw_engine* e, int width, int height)
 // staged — always correct, at the cost of one memcpy.  No runtime query per submit (each one also cost ~1 KB of host
 // memory that never came back: DESIGN.md §7 "Soak").
 struct PinRegistry {
+    enum Kind { ALLOC = 1, REGISTERED = 2 };  // how the range was page-locked: decides which HIP call releases it
+    struct Range {
+        size_t bytes;
+        int kind;
+    };
     std::mutex m;
-    std::map<uintptr_t, size_t> ranges;  // start -> bytes
-    void add(const void* p, size_t n)
+    std::map<uintptr_t, Range> ranges;  // start -> bytes, kind
+    void add(const void* p, size_t n, int kind)
     {
         std::lock_guard<std::mutex> lk(m);
-        ranges[(uintptr_t)p] = n;
+        ranges[(uintptr_t)p] = Range{n, kind};
     }
-    bool remove(const void* p)
+    // removes the range that STARTS at p if it was made the same way; 0 = removed, 1 = unknown, 2 = the other kind
+    // (tw_host_free on a registered block must not reach hipHostFree on the caller's malloc memory)
+    int remove(const void* p, int kind)
     {
         std::lock_guard<std::mutex> lk(m);
-        return ranges.erase((uintptr_t)p) > 0;
+        auto it = ranges.find((uintptr_t)p);
+        if (it == ranges.end()) return 1;
+        if (it->second.kind != kind) return 2;
+        ranges.erase(it);
+        return 0;
     }
     bool covers(const void* p, size_t n)
     {
@@ -1365,7 +1387,7 @@ struct PinRegistry {
         auto it = ranges.upper_bound((uintptr_t)p);
         if (it == ranges.begin()) return false;
         --it;
-        return (uintptr_t)p >= it->first && (uintptr_t)p + n <= it->first + it->second;
+        return (uintptr_t)p >= it->first && (uintptr_t)p + n <= it->first + it->second.bytes;
     }
 };
 PinRegistry& pin_registry()
@@ -1873,16 +1895,17 @@ tw_status tw_host_alloc(tw_engine* e, size_t bytes, void** hptr)
     if (!e || !hptr) return TW_E_BAD_PARAMETER;
     TW_HIP(e, hipSetDevice(e->device));
     TW_HIP(e, hipHostMalloc(hptr, bytes, hipHostMallocPortable));  // usable by the engines of every device (one queue, N consumers)
-    pin_registry().add(*hptr, bytes);
+    pin_registry().add(*hptr, bytes, PinRegistry::ALLOC);
     return TW_OK;
 }
 tw_status tw_host_free(tw_engine* e, void* hptr)
 {
     if (!e) return TW_E_BAD_PARAMETER;
     TW_HIP(e, hipSetDevice(e->device));
-    TW_HIP(e, hipStreamSynchronize(e->copy_stream));  // an upload may still be reading it
-    if (!pin_registry().remove(hptr)) {
-        e->err = "tw_host_free: not a tw_host_alloc block";
+    TW_HIP(e, hipStreamSynchronize(e->copy_stream));  // an upload of THIS engine may still be reading it (see twflow.h)
+    if (const int why = pin_registry().remove(hptr, PinRegistry::ALLOC)) {
+        e->err = why == 2 ? "tw_host_free: the block was registered (tw_host_register): release it with tw_host_unregister"
+                          : "tw_host_free: not a tw_host_alloc block";
         return TW_E_BAD_PARAMETER;
     }
     TW_HIP(e, hipHostFree(hptr));
@@ -1893,7 +1916,7 @@ tw_status tw_host_register(tw_engine* e, void* hptr, size_t bytes)
     if (!e || !hptr || !bytes) return TW_E_BAD_PARAMETER;
     TW_HIP(e, hipSetDevice(e->device));
     TW_HIP(e, hipHostRegister(hptr, bytes, hipHostRegisterPortable));
-    pin_registry().add(hptr, bytes);
+    pin_registry().add(hptr, bytes, PinRegistry::REGISTERED);
     return TW_OK;
 }
 tw_status tw_host_unregister(tw_engine* e, void* hptr)
@@ -1901,8 +1924,9 @@ tw_status tw_host_unregister(tw_engine* e, void* hptr)
     if (!e || !hptr) return TW_E_BAD_PARAMETER;
     TW_HIP(e, hipSetDevice(e->device));
     TW_HIP(e, hipStreamSynchronize(e->copy_stream));
-    if (!pin_registry().remove(hptr)) {
-        e->err = "tw_host_unregister: not a registered block";
+    if (const int why = pin_registry().remove(hptr, PinRegistry::REGISTERED)) {
+        e->err = why == 2 ? "tw_host_unregister: the block came from tw_host_alloc: release it with tw_host_free"
+                          : "tw_host_unregister: not a registered block";
         return TW_E_BAD_PARAMETER;
     }
     TW_HIP(e, hipHostUnregister(hptr));

@@ -41,6 +41,24 @@ __device__ __forceinline__ gptr_f sgpr_base_w(float* p)
     return g;
 }
 __device__ __forceinline__ void gstore(gptr_f row, unsigned byte_off, float v) { *(gptr_f)((gptr_c)row + byte_off) = v; }
+// Cache policy of the once-per-launch streams (round 4 A/B, -DTW_NT=<bits>): bit 0 the M planes a launch writes (read
+// again only by the NEXT launch, a whole batch later), bit 1 the R0 coefficients (read once per launch), bit 2 the R planes
+// polyexp writes.  Non-temporal = the `nt` bit of the global load / store: values are unchanged.
+#ifndef TW_NT
+#define TW_NT 0
+#endif
+template <int BIT, typename T>
+__device__ __forceinline__ void st_stream(T* p, T v)
+{
+    if constexpr ((TW_NT >> BIT) & 1) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+template <int BIT>
+__device__ __forceinline__ float ld_stream(const float* p)
+{
+    if constexpr ((TW_NT >> BIT) & 1) return __builtin_nontemporal_load(p);
+    else return *p;
+}
 
 // Raw buffer access: one resource descriptor (4 SGPRs) per image set, a wave-uniform 32-bit byte offset in
 // an SGPR (row / plane) and the lane's column as a 32-bit VGPR byte offset.  No per-load VALU address math
@@ -1130,7 +1148,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
             float* d = dst + (long long)(y + q) * a.ld + x;
             if (x + 1 < a.w) {
 #pragma unroll
-                for (int pl = 0; pl < 5; pl++) *(f32x2*)(d + pl * a.ps) = o[pl][q];
+                for (int pl = 0; pl < 5; pl++) st_stream<2>((f32x2*)(d + pl * a.ps), o[pl][q]);
             } else {
 #pragma unroll
                 for (int pl = 0; pl < 5; pl++) d[pl * a.ps] = o[pl][q][0];
@@ -1314,7 +1332,7 @@ __global__ __launch_bounds__(256) void tw_update_matrices(UpdArgs a)
         yy[j] = min(yb + 4 * j, a.h - 1);  // rows past the bottom repeat the last one (their stores are skipped)
         o[j] = (long long)yy[j] * a.ld + x;
 #pragma unroll
-        for (int c = 0; c < 5; c++) q[j][c] = R0[o[j] + c * a.ps];
+        for (int c = 0; c < 5; c++) q[j][c] = ld_stream<1>(R0 + o[j] + c * a.ps);
     }
     if (UPSAMPLE) {
         const int sx = a.xofs[x];
@@ -1374,7 +1392,7 @@ __global__ __launch_bounds__(256) void tw_update_matrices(UpdArgs a)
                 flow[o[j] + a.fps] = dy[j];
             }
 #pragma unroll
-            for (int c = 0; c < 5; c++) Mo[o[j] + c * a.ps] = M[j][c];
+            for (int c = 0; c < 5; c++) st_stream<0>(Mo + o[j] + c * a.ps, M[j][c]);
         }
     }
 }
@@ -1518,7 +1536,7 @@ __global__ __launch_bounds__(COLS) __attribute__((amdgpu_waves_per_eu(4, 8))) vo
                 const int xc = clampi(x0 + cx, 0, a.w - 1), yc = min(y0 + r, a.h - 1);
                 const long long o = (long long)yc * a.ld + xc;
 #pragma unroll
-                for (int cc = 0; cc < 5; cc++) qpre[i][cc] = R0p[o + cc * a.ps];
+                for (int cc = 0; cc < 5; cc++) qpre[i][cc] = ld_stream<1>(R0p + o + cc * a.ps);
             }
         }
     }
@@ -1630,7 +1648,7 @@ __global__ __launch_bounds__(COLS) __attribute__((amdgpu_waves_per_eu(4, 8))) vo
                 else update_matrices_px(R0, R1, a.ps, a.ld, a.w, a.h, xc, yc, fxv, fyv, M);
                 if (valid) {
 #pragma unroll
-                    for (int cc = 0; cc < 5; cc++) Mout[o + cc * a.ps] = M[cc];
+                    for (int cc = 0; cc < 5; cc++) st_stream<0>(Mout + o + cc * a.ps, M[cc]);
                 }
             }
         }

@@ -176,7 +176,11 @@ napi_value construct(napi_env env, napi_callback_info info)
     tw_default_params(&p.optParam);
     p.threshold = get_f64(env, opts, "threshold", 5.0);
     p.span = get_i32(env, opts, "span", 10);
-    p.numThreads = get_i32(env, opts, "numThreads", 4);
+    // The reference's default is 4 consumer threads (src/broker.cpp:109).  Here a consumer is a GPU worker, so a caller
+    // that passes no numThreads gets one per device the box has (on an 8-GPU node the default used to
+    // drive four cards); 4 only when no device answers (every job then reports the missing device).
+    const int ndev_default = tw_device_count();
+    p.numThreads = get_i32(env, opts, "numThreads", ndev_default > 0 ? ndev_default : 4);
     p.optParam.pyrScale = get_f64(env, opts, "pyrScale", 0.5);
     p.optParam.pyrLevels = get_i32(env, opts, "pyrLevels", 3);
     p.optParam.winSize = get_i32(env, opts, "winSize", 30);

@@ -28,7 +28,13 @@ int twt_load_gray(const char* path, uint8_t* out, size_t cap, int* w, int* h)
 {
     std::vector<uint8_t> img;
     int ww = 0, hh = 0;
-    if (!twhost::load_gray(path, img, ww, hh) || img.size() != (size_t)ww * hh) return 0;
+    const bool ok = twhost::load_gray(path, img, ww, hh);
+    if (!ok) {  // what a failed decode reports as its size (must be 0 x 0: it used to size the page-locked arena)
+        *w = ww;
+        *h = hh;
+        return 0;
+    }
+    if (img.size() != (size_t)ww * hh) return 0;
     *w = ww;
     *h = hh;
     memcpy(out, img.data(), img.size() < cap ? img.size() : cap);

@@ -11,8 +11,10 @@
 #include <sched.h>
 
 #include <algorithm>
+#include <chrono>
 #include <fstream>
 #include <memory>
+#include <mutex>
 #include <new>
 #include <sstream>
 
@@ -181,6 +183,16 @@ static bool decode_pnm(const std::vector<uint8_t>& d, std::vector<uint8_t>& img,
     if (w < 1 || h < 1 || w > 32768 || h > 32768 || maxval < 1 || maxval > 255) return false;
     if (!ascii) p++;  // a single whitespace byte ends the header of the binary kinds
     const size_t npx = (size_t)w * h;
+    {
+        // the payload must be able to hold the image the header announces BEFORE anything of that size is allocated
+        // (a 20-byte file with a 32768 x 32768 header used to cost 1 GiB of zero-filled memory per decode
+        // thread): binary kinds exactly; ASCII kinds at least one character per sample (P1) or a digit and a
+        // separator per sample but the last (P2 / P3)
+        const size_t rest = p < d.size() ? d.size() - p : 0;
+        const size_t samples = npx * (colour ? 3 : 1);
+        const size_t least = !ascii ? (bitmap ? (((size_t)w + 7) / 8) * (size_t)h : samples) : bitmap ? samples : 2 * samples - 1;
+        if (rest < least) return false;
+    }
     img.resize(npx);
     uint8_t scale[256];
     for (int i = 0; i <= maxval; i++) scale[i] = (uint8_t)(i * 255 / maxval);
@@ -286,6 +298,35 @@ static inline uint8_t rgb_to_gray(int r, int g, int b)
     return (uint8_t)((9797 * r + 19234 * g + 3737 * b) >> 15);
 }
 
+// CRC-32 of PNG chunks (ISO 3309, reflected 0xEDB88320), slicing-by-8: ~1 % of a decode
+static uint32_t png_crc32(const uint8_t* p, size_t n)
+{
+    static uint32_t T[8][256];
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (uint32_t i = 0; i < 256; i++) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; k++) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+            T[0][i] = c;
+        }
+        for (uint32_t i = 0; i < 256; i++)
+            for (int t = 1; t < 8; t++) T[t][i] = (T[t - 1][i] >> 8) ^ T[0][T[t - 1][i] & 0xFF];
+    });
+    uint32_t c = 0xFFFFFFFFu;
+    while (n >= 8) {
+        uint32_t a, b;
+        memcpy(&a, p, 4);
+        memcpy(&b, p + 4, 4);
+        a ^= c;
+        c = T[7][a & 0xFF] ^ T[6][(a >> 8) & 0xFF] ^ T[5][(a >> 16) & 0xFF] ^ T[4][a >> 24] ^ T[3][b & 0xFF] ^
+            T[2][(b >> 8) & 0xFF] ^ T[1][(b >> 16) & 0xFF] ^ T[0][b >> 24];
+        p += 8;
+        n -= 8;
+    }
+    while (n--) c = T[0][(c ^ *p++) & 0xFF] ^ (c >> 8);
+    return c ^ 0xFFFFFFFFu;
+}
+
 static bool decode_png(const std::vector<uint8_t>& d, std::vector<uint8_t>& img, int& w, int& h)
 {
     static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
@@ -293,14 +334,24 @@ static bool decode_png(const std::vector<uint8_t>& d, std::vector<uint8_t>& img,
     size_t p = 8;
     int depth = 0, ctype = 0, interlace = 0;
     std::vector<uint8_t> idat, plte;
-    bool have_ihdr = false;
+    bool have_ihdr = false, idat_done = false, first = true;
+    // Chunk rules the way libpng (cv::imread) enforces them — a file it refuses answers "Can't open" here as well
+    // (ADVICE r3): IHDR first; the CRC of every CRITICAL chunk (IHDR, PLTE, IDAT; an upper-case first letter) must
+    // hold — a mismatch there is png_error, in an ancillary chunk only a warning; IDAT chunks are consecutive; PLTE
+    // comes before IDAT.
     while (p + 12 <= d.size()) {
         const uint32_t len = be32(&d[p]);
         const char* type = (const char*)&d[p + 4];
         if (p + 12 + (size_t)len > d.size()) return false;
         const uint8_t* data = &d[p + 8];
+        const bool critical = !(type[0] & 0x20);
+        if (critical && memcmp(type, "IEND", 4) != 0 && png_crc32(&d[p + 4], 4 + (size_t)len) != be32(data + len)) return false;
+        if (first && memcmp(type, "IHDR", 4) != 0) return false;
+        first = false;
+        const bool is_idat = !memcmp(type, "IDAT", 4);
+        if (!is_idat && !idat.empty()) idat_done = true;
         if (!memcmp(type, "IHDR", 4)) {
-            if (len < 13) return false;
+            if (len < 13 || have_ihdr) return false;
             w = (int)be32(data);
             h = (int)be32(data + 4);
             depth = data[8];
@@ -308,8 +359,10 @@ static bool decode_png(const std::vector<uint8_t>& d, std::vector<uint8_t>& img,
             interlace = data[12];
             have_ihdr = true;
         } else if (!memcmp(type, "PLTE", 4)) {
+            if (!idat.empty()) return false;
             plte.assign(data, data + len);
-        } else if (!memcmp(type, "IDAT", 4)) {
+        } else if (is_idat) {
+            if (idat_done) return false;  // IDATs must be consecutive
             idat.insert(idat.end(), data, data + len);
         } else if (!memcmp(type, "IEND", 4)) {
             break;
@@ -343,6 +396,9 @@ static bool decode_png(const std::vector<uint8_t>& d, std::vector<uint8_t>& img,
     }
     // (uninitialised: every byte is written by the inflate or the decode fails; + 8 bytes of slack for nothing — the
     // decoder never writes past `total`)
+    // DEFLATE expands by at most 1032 : 1: a stream too short for the image the header announces is refused before
+    // `total` bytes (up to 8 GiB for 32768 x 32768 RGBA16) are allocated for it
+    if (total / 1032 > idat.size()) return false;
     std::unique_ptr<uint8_t[]> raw_buf(new (std::nothrow) uint8_t[total + 8]);
     if (!raw_buf) return false;
     uint8_t* const raw = raw_buf.get();
@@ -405,12 +461,21 @@ static bool decode_png(const std::vector<uint8_t>& d, std::vector<uint8_t>& img,
 bool load_gray(const std::string& path, std::vector<uint8_t>& img, int& w, int& h)
 {
     std::vector<uint8_t> d;
+    w = h = 0;
     if (!read_file(path, d) || d.size() < 8) return false;
-    if (d[0] == 'P' && d[1] >= '1' && d[1] <= '6') return decode_pnm(d, img, w, h);
-    if (d[0] == 0x89 && d[1] == 'P') return decode_png(d, img, w, h);
-    if (d[0] == 0xFF && d[1] == 0xD8) return decode_jpeg_gray(d.data(), d.size(), img, w, h);
-    if (d[0] == 'B' && d[1] == 'M') return decode_bmp(d, img, w, h);
-    return false;  // the other cv::imread formats (TIFF, JPEG-2000, Sun raster, ...) are not decoded
+    bool ok = false;
+    if (d[0] == 'P' && d[1] >= '1' && d[1] <= '6') ok = decode_pnm(d, img, w, h);
+    else if (d[0] == 0x89 && d[1] == 'P') ok = decode_png(d, img, w, h);
+    else if (d[0] == 0xFF && d[1] == 0xD8) ok = decode_jpeg_gray(d.data(), d.size(), img, w, h);
+    else if (d[0] == 'B' && d[1] == 'M') ok = decode_bmp(d, img, w, h);
+    // (the other cv::imread formats — TIFF, JPEG-2000, Sun raster, ... — are not decoded: INTEGRATION.md)
+    if (!ok) {
+        // the decoders write w / h from the header before they can fail: a failed decode reports no size (ADVICE r3:
+        // a 32768 x 32768 IHDR over a truncated IDAT used to size the page-locked arena)
+        w = h = 0;
+        std::vector<uint8_t>().swap(img);
+    }
+    return ok;
 }
 
 // cv::resize on CV_8UC1, INTER_LINEAR, 11-bit fixed point (imgproc/imgwarp.cpp: HResizeLinear<uchar,int,short>,
@@ -478,6 +543,10 @@ void Consumer::join()
 }
 
 namespace {
+inline long long steady_ns()
+{
+    return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 struct Staged {
     Request req;
     std::vector<uint8_t> a, b;
@@ -623,6 +692,7 @@ void Consumer::run()
         }
         TW_LOGF("finish optical flow: %g\n", (double)res.time);  // src/consumer.cpp:55
         mine.pairs++;
+        mine.lastResponseNs = steady_ns();
         publish();  // before the response leaves: whoever has seen N responses sees N pairs in the stats
         res_.push(std::move(res));
     };
@@ -645,7 +715,9 @@ void Consumer::run()
             finish_all(prev);  // nothing queued: deliver what is outstanding before blocking
             read_prof(true);   // idle: nothing of ours is in flight, so the event read's synchronise costs nothing
             publish();
+            const long long w0 = steady_ns();
             if (!req_.tryPop(first)) break;
+            if (mine.firstJobNs) mine.waitMs += (double)(steady_ns() - w0) * 1e-6;  // blocked on an empty queue
         }
         if (shared_ && shared_->epoch.load() != my_epoch) {
             // Manager::markEpoch(): counters restart here (the manager marks an epoch only while the queue is empty
@@ -653,9 +725,12 @@ void Consumer::run()
             my_epoch = shared_->epoch.load();
             read_prof(false);
             mine.pairs = mine.batches = 0;
+            mine.firstJobNs = mine.lastResponseNs = 0;
+            mine.waitMs = 0;
             mine.profMs[0] = mine.profMs[1] = 0;
             mine.profLaunches[0] = mine.profLaunches[1] = 0;
         }
+        if (!mine.firstJobNs) mine.firstJobNs = steady_ns();
         std::vector<Staged> jobs(1);
         jobs[0].req = std::move(first);
         // a consumer takes at most its share of what is queued, so that a short queue is spread over all GPUs
@@ -696,18 +771,29 @@ void Consumer::run()
             // copy tw_submit_u8 makes of pageable images (2 x 2 MB per 1080p pair, on this one thread, batch after
             // batch) had become a quarter of a batch's time.  Two arenas alternate: the previous batch's is still
             // being uploaded from while this one fills.
+            parallel_for(jobs.size(), [&](size_t j) { prepare(jobs[j], tw[j], th[j], ea[j], eb[j]); });
+            // The arena is sized AFTER prepare(), over the pairs that decoded and reconciled (a header with
+            // huge dimensions over a damaged stream must not size it), and it is bounded: a pair larger than
+            // kArenaSlotMax, or one the bounded arena has no room for, keeps its pageable buffers (tw_submit_u8 stages
+            // those itself — always correct, one memcpy slower).
+            constexpr size_t kArenaSlotMax = (size_t)64 << 20;  // one 8192 x 8192 image
+            constexpr size_t kArenaMax = (size_t)4 << 30;       // per arena, two arenas per consumer
             size_t slot = 0;
-            for (size_t j = 0; j < jobs.size(); j++)
-                if (!jobs[j].req.raw.expect) slot = std::max(slot, ((size_t)jobs[j].w * jobs[j].h + 255) / 256 * 256);
+            for (const Staged& s : jobs) {
+                if (!s.err.empty() || s.req.raw.expect) continue;
+                const size_t nb = ((size_t)s.w * s.h + 255) / 256 * 256;
+                if (nb <= kArenaSlotMax) slot = std::max(slot, nb);
+            }
             Arena& ar = arena[arena_idx];
             arena_idx ^= 1;
-            const size_t need = slot * 2 * jobs.size();
-            if (eng && need > ar.cap) {
+            const size_t need = std::min(kArenaMax, slot * 2 * jobs.size());
+            if (eng && slot && need > ar.cap) {
                 if (ar.base) (void)tw_host_free(eng, ar.base);
                 ar.base = nullptr;
                 ar.cap = 0;
                 void* hp = nullptr;
-                const size_t want = std::max(need, slot * 2 * (size_t)batch_);  // a full batch of this size: no regrowth
+                // a full batch of this size (no regrowth), within the bound
+                const size_t want = std::min(kArenaMax, std::max(need, slot * 2 * (size_t)batch_));
                 if (tw_host_alloc(eng, want, &hp) == TW_OK) {
                     ar.base = (uint8_t*)hp;
                     ar.cap = want;
@@ -715,9 +801,9 @@ void Consumer::run()
             }
             parallel_for(jobs.size(), [&](size_t j) {
                 Staged& s = jobs[j];
-                prepare(s, tw[j], th[j], ea[j], eb[j]);
-                if (!s.err.empty() || s.req.raw.expect || !ar.base || (2 * j + 2) * slot > ar.cap) return;
+                if (!s.err.empty() || s.req.raw.expect || !ar.base || !slot) return;
                 const size_t nb = (size_t)s.w * s.h;
+                if (nb > slot || (2 * j + 2) * slot > ar.cap) return;  // stays pageable
                 uint8_t* da = ar.base + slot * (2 * j);
                 uint8_t* db = da + slot;
                 memcpy(da, s.a.data(), nb);

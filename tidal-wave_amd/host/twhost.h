@@ -76,6 +76,11 @@ struct ConsumerStats {
     // event-bracketed level-0 launches since then: [0] window average + solve, [1] polynomial expansion
     double profMs[2] = {0, 0};
     int profLaunches[2] = {0, 0};
+    // when the consumer worked since then (std::chrono::steady_clock, nanoseconds since its epoch): pop of its first
+    // job, push of its last response, and the time it sat blocked on an EMPTY request queue in between — a driver
+    // that knows its own clock derives each consumer's idle time from these (tools/bench_queue.cpp)
+    long long firstJobNs = 0, lastResponseNs = 0;
+    double waitMs = 0;
     // placement of the consumer thread (and, by inheritance / first touch, of its decode pool and of the page-locked
     // buffers its engine allocates): NUMA node of the GPU, -1 = not bound (TW_NUMA=0, no NUMA information, or none
     // of the node's CPUs is available to this process)

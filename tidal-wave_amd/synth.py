@@ -59,9 +59,10 @@ def warp(expect, rng):
     return warp_with_flow(expect, rng)[0]
 
 
-def warp_with_flow(expect, rng):
+def warp_with_flow(expect, rng, amp=1.0):
     """(target, vx, vy): target(x, y) = expect(x - vx, y - vy), bilinear; the flow a perfect estimator would report at
-    (x, y) for the pair (expect, target) is ~(vx, vy) there (exactly v at the matched position; v is smooth)."""
+    (x, y) for the pair (expect, target) is ~(vx, vy) there (exactly v at the matched position; v is smooth).
+    |v| <= 6 * amp pixels per component (amp = 8: the 48-px warps of bench.py's input-sensitivity extra)."""
     h, w = expect.shape
     yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
     vx = np.zeros((h, w))
@@ -69,7 +70,7 @@ def warp_with_flow(expect, rng):
     for _ in range(3):
         fx, fy = rng.uniform(0.5, 2.0, 2)
         ph = rng.uniform(0, 2 * np.pi, 2)
-        ax, ay = rng.uniform(-2, 2, 2)
+        ax, ay = rng.uniform(-2, 2, 2) * amp
         vx += ax * np.sin(2 * np.pi * fx * xx / w + ph[0]) * np.cos(2 * np.pi * fy * yy / h)
         vy += ay * np.cos(2 * np.pi * fx * xx / w) * np.sin(2 * np.pi * fy * yy / h + ph[1])
     sx = np.clip(xx - vx, 0, w - 1)
@@ -85,13 +86,14 @@ def warp_with_flow(expect, rng):
     return np.clip(np.rint(out), 0, 255).astype(np.uint8), vx, vy
 
 
-def make_pair(index, h=1080, w=1920, kind=None, with_flow=False):
-    """Returns (expect, target) uint8 [h,w]; with_flow: (expect, target, vx, vy) for the warped kinds (0, 1)."""
+def make_pair(index, h=1080, w=1920, kind=None, with_flow=False, amp=1.0):
+    """Returns (expect, target) uint8 [h,w]; with_flow: (expect, target, vx, vy) for the warped kinds (0, 1).
+    kind overrides index % 4; amp scales the warp (kinds 0, 1)."""
     rng = np.random.default_rng(BASE_SEED + index)
     expect = make_expect(rng, h, w)
     k = index % 4 if kind is None else kind
     if k in (0, 1):
-        target, vx, vy = warp_with_flow(expect, rng)
+        target, vx, vy = warp_with_flow(expect, rng, amp)
         if with_flow:
             return expect, target, vx, vy
     elif k == 2:

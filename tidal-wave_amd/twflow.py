@@ -69,6 +69,8 @@ def lib():
     path = LIB_PATH
     if os.environ.get("TWFLOW_VARIANTS") == "1":
         path = VARIANTS_LIB_PATH  # tools/ A/B runs (kbench, sq_probe) of the kernels the product library leaves out
+    if os.environ.get("TWFLOW_LIB"):
+        path = os.environ["TWFLOW_LIB"]  # tools/ A/B runs of another BUILD of the library (e.g. make NT=<bits>)
     if not os.path.exists(path):
         raise ImportError("%s not built: run `python -c 'import __graft_entry__ as g; g.build()'`" % os.path.basename(path))
     _lib = _bind(path)
@@ -264,6 +266,13 @@ class Engine:
         h, w = a.shape
         tk = C.c_int64()
         self._check(self._L.tw_submit_u8(self._h, _u8(a), _u8(b), w, h, a.strides[0], span, threshold, C.byref(tk)))
+        return (tk.value, w, h, span, threshold)
+
+    def submit_ptr(self, p_expect, p_target, w, h, stride, span=10, threshold=5.0):
+        """tw_submit_u8 on raw HOST pointers (ctypes POINTER(c_uint8)) the caller keeps alive — the bench's inner loop:
+        no numpy marshalling per pair.  Page-locked memory (host_array) is DMAed in place."""
+        tk = C.c_int64()
+        self._check(self._L.tw_submit_u8(self._h, p_expect, p_target, w, h, stride, span, threshold, C.byref(tk)))
         return (tk.value, w, h, span, threshold)
 
     def submit_dev(self, d_expect, d_target, w, h, stride, span=10, threshold=5.0):

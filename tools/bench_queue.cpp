@@ -223,7 +223,9 @@ int main(int argc, char** argv)
     const auto t0 = std::chrono::steady_clock::now();
     for (long j = 0; j < a.pairs; j++) push(warm + j);
     wait_done(warm + a.pairs);
-    const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    const auto t1 = std::chrono::steady_clock::now();
+    const double sec = std::chrono::duration<double>(t1 - t0).count();
+    const long long t0_ns = std::chrono::duration_cast<std::chrono::nanoseconds>(t0.time_since_epoch()).count();
 
     mg->stop();
     {
@@ -247,11 +249,19 @@ int main(int argc, char** argv)
            first_error.c_str(), warm, rounds, all_warm ? "true" : "false");
     for (size_t i = 0; i < stats.size(); i++) {
         const ConsumerStats& cs = stats[i];
+        // idle = the part of the timed region this consumer did not work in: before its first job, after its last
+        // response, and blocked on an empty queue in between (at N = 8 a starved consumer must show)
+        const double start_ms = cs.firstJobNs ? (double)(cs.firstJobNs - t0_ns) * 1e-6 : sec * 1e3;
+        const double active_ms = cs.firstJobNs && cs.lastResponseNs > cs.firstJobNs
+                                     ? (double)(cs.lastResponseNs - cs.firstJobNs) * 1e-6 - cs.waitMs : 0.0;
+        const double idle_ms = std::max(0.0, sec * 1e3 - active_ms);
         printf("%s{\"id\": %d, \"device\": %d, \"pci\": \"%s\", \"numa_node\": %d, \"cpus\": %zu, \"pairs\": %ld, "
                "\"batches\": %ld, \"blur_l0_ms\": %.4f, \"blur_l0_launches\": %d, \"polyexp_l0_ms\": %.4f, "
-               "\"polyexp_l0_launches\": %d}",
+               "\"polyexp_l0_launches\": %d, \"first_job_ms\": %.3f, \"wait_ms\": %.3f, \"idle_ms\": %.3f, "
+               "\"idle_frac\": %.4f}",
                i ? ", " : "", cs.id, cs.device, cs.pciBusId.c_str(), cs.numaNode, cs.cpus.size(), cs.pairs, cs.batches,
-               cs.profMs[0], cs.profLaunches[0], cs.profMs[1], cs.profLaunches[1]);
+               cs.profMs[0], cs.profLaunches[0], cs.profMs[1], cs.profLaunches[1], start_ms, cs.waitMs, idle_ms,
+               idle_ms / (sec * 1e3));
     }
     printf("]}\n");
     return errors ? 1 : 0;

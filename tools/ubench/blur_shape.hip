@@ -108,6 +108,122 @@ __global__ __launch_bounds__(256) void krefresh2(const float* __restrict__ R, fl
         }
     }
 }
+// ROLLING WINDOW (round 4): a workgroup marches NT tiles down its column strip and keeps the window, so
+// every M row enters the CU once: per step only the TH new rows of each plane are loaded (NT*TH + 2*MH rows per NT*TH
+// output rows instead of 38 per 8).  The S phase is the refreshing launch's, unchanged.  No LDS, no arithmetic, the
+// occupancy of the real kernel (256 threads, 4 workgroups per CU): the most a rolling structure could gain.
+//   DMA = true: the new rows go to LDS by LDS-DMA (buffer_load ... lds, no VGPR round trip) and are read back from there.
+template <int NT, bool DMA, bool REFRESH>
+__global__ __launch_bounds__(256) void kroll(const float* __restrict__ Min, const float* __restrict__ R, float* __restrict__ Mout,
+                                             float* __restrict__ flow, long long ps)
+{
+    __shared__ __attribute__((aligned(16))) float ring[DMA ? 5 * TH * 256 : 1];
+    int bx, seg, z;
+    xcd_remap(bx, seg, z);
+    const int x0 = bx * TW - 16, tid = threadIdx.x;
+    const float* M = Min + (long long)z * 5 * ps;
+    const int xw = min(max(x0 - HALO + tid, 0), W - 1);
+    const bool von = x0 - HALO + tid >= -MH && x0 - HALO + tid <= W - 1 + MH;
+    const float* R0 = R + (long long)(2 * z) * 5 * ps;
+    const float* R1 = R0 + 5 * ps;
+    float* Mo = Mout + (long long)z * 5 * ps;
+    float* fl = flow + (long long)z * 2 * ps;
+    float acc = 0.f;
+    const int ys = seg * NT * TH;
+    // prologue: the 2*MH rows above the first new block
+    if (von) {
+#pragma unroll
+        for (int ch = 0; ch < 5; ch++) {
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(M + ch * ps), 0, 0xFFFFFFFFu, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < 2 * MH; i++) {
+                const unsigned ro = (unsigned)min(max(ys - MH + i, 0), H - 1) * (LD * 4u);
+                acc += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (unsigned)xw * 4u, ro, 0));
+            }
+        }
+    }
+#pragma unroll 1
+    for (int st = 0; st < NT; st++) {
+        const int y0 = ys + st * TH;
+        if (y0 >= H) break;
+        if (DMA) {
+            // one wave-instruction = one 256-byte row segment -> 256 consecutive LDS bytes (wave-uniform base + lane * 4)
+#pragma unroll
+            for (int ch = 0; ch < 5; ch++) {
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(M + ch * ps), 0, 0xFFFFFFFFu, 0x00020000);
+#pragma unroll
+                for (int i = 0; i < TH; i++) {
+                    const unsigned ro = (unsigned)min(max(y0 + MH + i, 0), H - 1) * (LD * 4u);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)&ring[(ch * TH + i) * 256 + (tid & ~63)], 4,
+                                                         (unsigned)xw * 4u, ro, 0, 0);
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0): the wave's own pieces have landed
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 5 * TH; j++) acc += ring[j * 256 + tid];
+            __syncthreads();
+        } else if (von) {
+#pragma unroll
+            for (int ch = 0; ch < 5; ch++) {
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(M + ch * ps), 0, 0xFFFFFFFFu, 0x00020000);
+#pragma unroll
+                for (int i = 0; i < TH; i++) {
+                    const unsigned ro = (unsigned)min(max(y0 + MH + i, 0), H - 1) * (LD * 4u);
+                    acc += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (unsigned)xw * 4u, ro, 0));
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 7; i++) {
+            const int p = tid + i * 256, r = p / TW, cx = p - r * TW;
+            const int x = x0 + cx, y = y0 + r;
+            const bool valid = x >= 0 && x < W && y < H;
+            const int xc = min(max(x, 0), W - 2), yc = min(y, H - 2);
+            const long long o = (long long)yc * LD + xc;
+            if (!REFRESH) {
+                if (valid) {
+                    fl[o] = acc;
+                    fl[o + ps] = acc + 1.f;
+                }
+                continue;
+            }
+            float s = acc;
+#pragma unroll
+            for (int c = 0; c < 5; c++) {
+                s += R0[o + c * ps];
+                s += R1[o + c * ps] + R1[o + c * ps + 1] + R1[o + c * ps + LD] + R1[o + c * ps + LD + 1];
+            }
+            if (valid) {
+#pragma unroll
+                for (int c = 0; c < 5; c++) Mo[o + c * ps] = s + (float)c;
+            }
+        }
+    }
+}
+template <int NT, bool DMA, bool REFRESH>
+static void run_roll(const char* name, const float* M0, const float* R, float* M1, float* fl, long long ps, int np, int lds = 0)
+{
+    const int nseg = ((H + TH - 1) / TH + NT - 1) / NT;
+    const dim3 grid((W + 16 + TW - 1) / TW, nseg, np);
+    double best = 1e30;
+    for (int rep = 0; rep < 2; rep++) {
+        hipEvent_t a, b;
+        hipEventCreate(&a);
+        hipEventCreate(&b);
+        hipLaunchKernelGGL((kroll<NT, DMA, REFRESH>), grid, dim3(256), lds, 0, M0, R, M1, fl, ps);
+        hipEventRecord(a);
+        for (int i = 0; i < 10; i++) hipLaunchKernelGGL((kroll<NT, DMA, REFRESH>), grid, dim3(256), lds, 0, M0, R, M1, fl, ps);
+        hipEventRecord(b);
+        hipEventSynchronize(b);
+        float ms = 0;
+        hipEventElapsedTime(&ms, a, b);
+        best = ms * 1e3 / 10 < best ? ms * 1e3 / 10 : best;
+    }
+    const double bpp = REFRESH ? 80 : 28;
+    printf("rolling window, %-42s %8.1f us per %d pairs  %6.2f us/pair  %5.2f TB/s  (%d workgroups)\n", name, best, np, best / np,
+           bpp * W * H * np / best / 1e6, (int)(grid.x * grid.y * grid.z));
+}
 // window loads only, in other shapes: VEC floats per lane and load (b32 / b64 / b128: a wave then covers 64 * VEC columns),
 // ROWS output rows per tile (window = ROWS + 30 rows).  Same bytes per output row for a given ROWS.
 template <int VEC, int ROWS>
@@ -211,6 +327,24 @@ int main()
         printf("%-58s %8.1f us per 64 pairs  %6.2f us/pair  %5.2f TB/s\n", "refresh traffic alone, 2 pixels per lane (8-byte accesses)", u,
                u / np, 60.0 * px / u / 1e6);
     }
+    {
+        // the as-built shape again with the real kernel's residency (40 KB of LDS -> 4 workgroups per CU)
+        const double u = time_us([&] { hipLaunchKernelGGL(k<0>, grid, dim3(256), 40960, 0, M0, R, M1, fl, ps); }, 10);
+        printf("%-58s %8.1f us per 64 pairs  %6.2f us/pair\n", "refreshing launch as built, 4 workgroups per CU", u, u / np);
+    }
+    run_roll<5, false, true>("refreshing, NT=5 (40 rows)", M0, R, M1, fl, ps, np);
+    run_roll<15, false, true>("refreshing, NT=15 (120 rows)", M0, R, M1, fl, ps, np);
+    run_roll<27, false, true>("refreshing, NT=27 (216 rows)", M0, R, M1, fl, ps, np);
+    run_roll<45, false, true>("refreshing, NT=45 (360 rows)", M0, R, M1, fl, ps, np);
+    run_roll<135, false, true>("refreshing, NT=135 (whole column)", M0, R, M1, fl, ps, np);
+    run_roll<27, true, true>("refreshing, NT=27, new rows by LDS-DMA", M0, R, M1, fl, ps, np);
+    run_roll<135, true, true>("refreshing, NT=135, new rows by LDS-DMA", M0, R, M1, fl, ps, np);
+    run_roll<15, false, true>("refreshing, NT=15, 4 workgroups per CU", M0, R, M1, fl, ps, np, 40960);
+    run_roll<27, false, true>("refreshing, NT=27, 4 workgroups per CU", M0, R, M1, fl, ps, np, 40960);
+    run_roll<135, false, true>("refreshing, NT=135, 4 workgroups per CU", M0, R, M1, fl, ps, np, 40960);
+    run_roll<27, false, true>("refreshing, NT=27, 2 workgroups per CU", M0, R, M1, fl, ps, np, 65536);
+    run_roll<27, false, false>("last launch, NT=27", M0, R, M1, fl, ps, np);
+    run_roll<135, false, false>("last launch, NT=135", M0, R, M1, fl, ps, np);
     run_win<1, 8>("b32, 8-row tiles (as built)", M0, fl, ps, np);
     run_win<2, 8>("b64, 8-row tiles", M0, fl, ps, np);
     run_win<4, 8>("b128, 8-row tiles", M0, fl, ps, np);
