@@ -225,6 +225,7 @@ def roofline_obj(name, ms, launches, bytes_total, pairs_per_launch, traffic, chu
             "traffic_source": "profiles/traffic_latest.json (static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
                               "passes of an earlier run of this command, not a live counter; measured on launches "
                               "of traffic_pairs_per_launch pairs and scaled to this run's pairs per launch)",
+            "traffic_measured": traffic.get("_provenance"),
             "bytes_model": "what the kernel as built must move per launch (blur+solve: 80 B/px for a launch "
                            "fused with the matrix refresh, 28 B/px for the last one; polyexp 24 B/px)",
             "algorithmic_bytes_per_launch": bytes_total / launches,

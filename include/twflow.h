@@ -29,8 +29,9 @@ extern "C" {
 #endif
 
 /* 2 (round 3): + tw_device_pci_bus_id, tw_host_register / tw_host_unregister, tw_has_variants, TW_OPT_POLYEXP_F32.
+ * 3 (round 4): + tw_submit_png8 (PNG scanline reconstruction + gray conversion on the device).
  * Purely additive: a consumer built against version 1 runs unchanged. */
-#define TWFLOW_ABI_VERSION 2
+#define TWFLOW_ABI_VERSION 3
 
 /* Status codes.  The first four are enum ErrorCode of /root/reference/src/opticalflow.h:9-14. */
 typedef enum tw_status {
@@ -112,6 +113,16 @@ tw_status tw_diff_u8(tw_engine* e, const uint8_t* expect, const uint8_t* target,
  * flight per GPU).  The host images are copied to pinned staging before tw_submit_u8 returns. */
 tw_status tw_submit_u8(tw_engine* e, const uint8_t* expect, const uint8_t* target, int width, int height,
                        ptrdiff_t stride, int span, double threshold, tw_ticket* ticket);
+/* The same pair handed over HALF-DECODED (ABI 3): what cv::imread(path, GRAYSCALE) of src/opticalflow.cpp:37,44 does to
+ * an 8-bit non-interlaced PNG after the inflate — scanline reconstruction (filter types 0-4 of ISO/IEC 15948 §9) and
+ * libpng 1.5's RGB -> gray — runs on the device, so the host's decode threads only inflate.  For each
+ * image: channels 1 (gray), 2 (gray + alpha), 3 (RGB) or 4 (RGBA) = the inflated IDAT stream, `height` rows of
+ * 1 + width * channels bytes, filter type byte first; channels 0 = a plain gray image, dense rows of `width` bytes (so a
+ * pair may mix a PNG with an image the host decoded).  The result equals tw_submit_u8 on the host-decoded images bit for
+ * bit.  A filter type above 4 answers TW_E_BAD_IMAGE_FORMAT.  Page-locked buffers are DMA-ed in place like
+ * tw_submit_u8's (keep them until tw_wait); pageable ones are copied before the call returns. */
+tw_status tw_submit_png8(tw_engine* e, const uint8_t* expect, int expect_channels, const uint8_t* target,
+                         int target_channels, int width, int height, int span, double threshold, tw_ticket* ticket);
 /* Same with the images already resident in device memory (HBM) of the engine's device. */
 tw_status tw_submit_dev(tw_engine* e, const void* d_expect, const void* d_target, int width, int height,
                         ptrdiff_t stride, int span, double threshold, tw_ticket* ticket);
@@ -206,6 +217,10 @@ tw_status tw_bench_stage(tw_engine* e, int kclass, int width, int height, int le
  * Layouts: images/planes are dense row-major; R and M are 5 planes [5][h][w]; flow is 2 planes. */
 tw_status tw_stage_pyr_level(tw_engine* e, const uint8_t* img, int w0, int h0, int level, float* I, int* w,
                              int* h);
+/* PNG scanline reconstruction + gray conversion of one image (tw_submit_png8's kernel): `rows` = h rows of
+ * 1 + w * channels bytes, channels 1-4; `waves` = 0 (the engine's choice for this width), 1, 4 or 16 waves per image. */
+tw_status tw_stage_png_unfilter(tw_engine* e, const uint8_t* rows, int channels, int w, int h, int waves,
+                                uint8_t* gray);
 tw_status tw_stage_polyexp(tw_engine* e, const float* I, int w, int h, float* R5);
 tw_status tw_stage_update_matrices(tw_engine* e, const float* R0_5, const float* R1_5, const float* flow2,
                                    int w, int h, float* M5);

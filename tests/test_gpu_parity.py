@@ -527,7 +527,11 @@ def test_page_lock_table_is_process_wide_and_never_stale(twflow, oracle):
         e1._hostbufs = []
         assert L.tw_host_free(e2._h, C.c_void_p(addr_a)) == twflow.TW_E_BAD_PARAMETER   # not in the table any more
         # caller-owned memory: registered -> direct DMA, unregistered -> staged; both give the oracle's vectors
-        buf = np.empty((2,) + a.shape, np.uint8)
+        # (an anonymous page-aligned mapping of its own, not a block of the malloc heap: hipHostRegister pins whole pages,
+        # and pages of the heap are shared with — and later reused by — whatever else the process allocates)
+        import mmap
+        mm = mmap.mmap(-1, (2 * a.size + 4095) // 4096 * 4096)
+        buf = np.frombuffer(mm, np.uint8, 2 * a.size).reshape((2,) + a.shape)
         buf[0], buf[1] = a, b
         assert L.tw_host_register(e1._h, C.c_void_p(buf.ctypes.data), buf.nbytes) == twflow.TW_OK
         assert e1.wait(e1.submit(buf[0], buf[1], 10, 1.0))["vector"] == want

@@ -41,6 +41,9 @@ def lib():
     L.twt_adler32.restype = C.c_uint
     L.twt_unfilter.argtypes = [C.c_char_p, C.c_size_t, C.c_size_t, C.c_size_t]
     L.twt_load_gray.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.twt_load_rows.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                C.POINTER(C.c_int), C.POINTER(C.c_size_t)]
+    L.twt_finish_rows.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_char_p]
     return L
 
 
@@ -429,3 +432,61 @@ def test_png_chunk_rules_of_libpng_and_header_bounds(lib, tmp_path):
             assert not ok and w.value == 0 and h.value == 0, (name, ok, w.value, h.value)
     finally:
         resource.setrlimit(resource.RLIMIT_AS, (soft, hard))
+
+
+def test_half_decoded_png_rows_for_the_device(lib, tmp_path):
+    """tw_submit_png8's host side (round 4): for an 8-bit non-interlaced gray / gray+alpha / RGB / RGBA PNG the decode
+    pool stops after the inflate and hands the FILTERED rows over (the device reconstructs them); every other kind — palette,
+    16-bit, interlaced, sub-byte — and every other format comes back as gray pixels as before.  The rows are exactly
+    zlib's output of the IDAT stream, and finishing them on the host (the <= 5 px size-reconcile path) gives load_gray's
+    bytes."""
+    from PIL import Image
+    sys.path.insert(0, os.path.join(ROOT, "tidal-wave_amd"))
+    import synth
+    a, _ = synth.make_pair(1, 135, 241)
+    rgb = np.stack([a, np.roll(a, 3, 1), 255 - a], -1)
+
+    def rows_of(path):
+        out = C.create_string_buffer(1 << 22)
+        w, h, ch, n = C.c_int(), C.c_int(), C.c_int(), C.c_size_t()
+        if not lib.twt_load_rows(str(path).encode(), out, 1 << 22, C.byref(w), C.byref(h), C.byref(ch), C.byref(n)):
+            return None
+        return out.raw[:n.value], w.value, h.value, ch.value
+
+    def idat_stream(path):
+        d = open(path, "rb").read()
+        p, z = 8, b""
+        while p < len(d):
+            n = int.from_bytes(d[p:p + 4], "big")
+            if d[p + 4:p + 8] == b"IDAT":
+                z += d[p + 8:p + 8 + n]
+            p += 12 + n
+        return zlib.decompress(z)
+
+    for name, arr, ch in (("g", a, 1), ("rgb", rgb, 3), ("rgba", np.dstack([rgb, a]), 4), ("ga", np.dstack([a, 255 - a]), 2)):
+        p = tmp_path / (name + ".png")
+        Image.fromarray(arr, mode="LA" if ch == 2 else None).save(p, compress_level=4)
+        rows, w, h, got_ch = rows_of(p)
+        assert (w, h, got_ch) == (241, 135, ch) and rows == idat_stream(p), name
+        out = C.create_string_buffer(w * h)
+        assert lib.twt_finish_rows(rows, len(rows), w, h, ch, out)
+        assert np.array_equal(np.frombuffer(out.raw, np.uint8).reshape(h, w), _load(lib, p)), name
+    # kinds the device does not take: gray pixels, ch = 0, equal to load_gray
+    Image.fromarray(a).convert("P", palette=Image.ADAPTIVE, colors=16).save(tmp_path / "pal.png")
+    Image.fromarray((a.astype(np.uint16) << 8) | 0x33).save(tmp_path / "g16.png")
+    Image.fromarray(a).save(tmp_path / "j.jpg", quality=90)
+    Image.fromarray(a).save(tmp_path / "g.pgm")
+    for name in ("pal.png", "g16.png", "j.jpg", "g.pgm"):
+        rows, w, h, ch = rows_of(tmp_path / name)
+        assert ch == 0 and (w, h) == (241, 135), name
+        assert np.array_equal(np.frombuffer(rows, np.uint8).reshape(h, w), _load(lib, tmp_path / name)), name
+    # a filter type byte above 4 is refused here (libpng: "bad adaptive filter value"), as load_gray refuses it
+    good = bytearray(idat_stream(tmp_path / "g.png"))
+    good[3 * 242] = 7
+    d = bytearray(open(tmp_path / "g.png", "rb").read())
+    i = d.index(b"IDAT") - 4
+    n = int.from_bytes(d[i:i + 4], "big")
+    end = d.index(b"IEND") - 4
+    bad = bytes(d[:i]) + _png_chunk(b"IDAT", zlib.compress(bytes(good))) + bytes(d[end:])
+    (tmp_path / "badft.png").write_bytes(bad)
+    assert rows_of(tmp_path / "badft.png") is None and _load(lib, tmp_path / "badft.png") is None

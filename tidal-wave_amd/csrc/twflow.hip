@@ -248,6 +248,7 @@ struct Job {
     const uint8_t *d_a = nullptr, *d_b = nullptr;
     long long stride = 0;
     bool waited = false;
+    int png_ch[2] = {0, 0};  // tw_submit_png8: channels of the filtered rows staged in Ctx::d_filt (0: plain gray)
 };
 
 // One batch of pairs: host-side state that must outlive the asynchronous execution.
@@ -265,6 +266,13 @@ struct Ctx {
     uint8_t* d_img = nullptr;
     size_t d_img_cap = 0;
     hipEvent_t ev_h2d = nullptr;
+    // tw_submit_png8: filtered PNG rows of the batch (2 slots of filt_slot bytes per job) and the job table of
+    // tw_png_unfilter, which reconstructs them into d_img on the copy stream before ev_h2d
+    uint8_t* d_filt = nullptr;
+    size_t d_filt_cap = 0, filt_slot = 0;  // filt_slot: bytes per image of the open batch (0: no filtered image yet)
+    PngJob* d_png = nullptr;
+    PngJob* h_png = nullptr;  // pinned, [2*cap]
+    bool any_png = false;
     // ordered hit records of the batch [cap][G]: tw_wait reads them late when a pair has more than HOST_RECS hits,
     // so they belong to the context, not to the engine (a later batch must not overwrite them)
     ScanRec* d_rec = nullptr;
@@ -352,6 +360,8 @@ struct tw_engine {
     int win_m = 15;
     int box = 0;           // flags without 256: box window (FarnebackUpdateFlow_Blur), scan kernels
     double* Vd = nullptr;  // running column sums of the box window (5 double planes per pair of a chunk)
+    uint8_t* h_bounce = nullptr;  // pinned bounce buffer of tw_submit_png8's pageable inputs
+    size_t h_bounce_cap = 0;
     size_t Vd_cap = 0;
     int img_aligned4 = 0;  // every image pointer and the row stride of the batch being enqueued are 4-byte aligned
     int lanes = 1;         // TW_LANES=2: the two halves of a batch run on two streams (memory-bound kernels of one
@@ -1115,6 +1125,27 @@ tw_status flush_ctx(tw_engine* e, Ctx& c)
     RoctxRange batch_range("tw_batch %dx%d pairs=%d", c.w, c.h, n);
     const size_t npx = staged_image_bytes(c.w, c.h);  // staged images are 256-byte aligned
     long long stride = c.jobs[0].stride;
+    if (c.any_png) {
+        // tw_submit_png8: reconstruct the filtered rows into the gray image slots, on the copy stream behind the
+        // uploads — it runs beside the previous batch's kernels like the uploads themselves
+        for (int j = 0; j < n; j++)
+            for (int q = 0; q < 2; q++) {
+                PngJob& pj = c.h_png[2 * j + q];
+                pj.ch = c.jobs[j].png_ch[q];
+                pj.src = c.d_filt ? c.d_filt + c.filt_slot * (size_t)(2 * j + q) : nullptr;
+                pj.dst = c.d_img + npx * (size_t)(2 * j + q);
+                pj.pad = 0;
+            }
+        TW_HIP(e, hipMemcpyAsync(c.d_png, c.h_png, sizeof(PngJob) * 2 * (size_t)n, hipMemcpyHostToDevice, e->copy_stream));
+        PngArgs pa;
+        pa.jobs = c.d_png;
+        pa.w = c.w;
+        pa.h = c.h;
+        // waves per image: as many as the 128 KB of LDS row buffers allow for this width
+        if (c.w <= PNG_LDS_PIXELS / 16) hipLaunchKernelGGL(tw_png_unfilter<16>, dim3(2 * n), dim3(1024), 0, e->copy_stream, pa);
+        else if (c.w <= PNG_LDS_PIXELS / 4) hipLaunchKernelGGL(tw_png_unfilter<4>, dim3(2 * n), dim3(256), 0, e->copy_stream, pa);
+        else hipLaunchKernelGGL(tw_png_unfilter<1>, dim3(2 * n), dim3(64), 0, e->copy_stream, pa);
+    }
     if (c.any_host) {
         // the uploads were queued on the copy stream as the jobs came in (submit_common)
         TW_HIP(e, hipEventRecord(c.ev_h2d, e->copy_stream));
@@ -1396,8 +1427,12 @@ PinRegistry& pin_registry()
     return r;
 }
 
+size_t png_rows_bytes(int width, int height, int ch) { return (size_t)height * ((size_t)width * (size_t)ch + 1); }
+
+// ch_a / ch_b > 0 (tw_submit_png8): that host image is `height` filtered PNG rows of 1 + width * ch bytes
 tw_status submit_common(tw_engine* e, const uint8_t* h_a, const uint8_t* h_b, const void* d_a, const void* d_b,
-                        int width, int height, ptrdiff_t stride, int span, double threshold, tw_ticket* ticket)
+                        int width, int height, ptrdiff_t stride, int span, double threshold, tw_ticket* ticket,
+                        int ch_a = 0, int ch_b = 0)
 {
     if (!e) return TW_E_BAD_PARAMETER;
     e->err.clear();
@@ -1407,14 +1442,37 @@ tw_status submit_common(tw_engine* e, const uint8_t* h_a, const uint8_t* h_b, co
         e->err = "bad argument";
         return TW_E_BAD_PARAMETER;
     }
+    const bool png = ch_a > 0 || ch_b > 0;
+    if (png) {
+        if (!h_a || !h_b || ch_a < 0 || ch_a > 4 || ch_b < 0 || ch_b > 4 || stride != width) {
+            e->err = "bad argument";
+            return TW_E_BAD_PARAMETER;
+        }
+        // the filter type byte of every row (ISO/IEC 15948 §9.2: 0-4): checked here, on the host, so that the kernel
+        // never has to answer for a damaged stream (libpng: "bad adaptive filter value" -> imread fails)
+        const uint8_t* img[2] = {h_a, h_b};
+        const int chs[2] = {ch_a, ch_b};
+        for (int q = 0; q < 2; q++) {
+            if (!chs[q]) continue;
+            const size_t rs = (size_t)width * (size_t)chs[q] + 1;
+            for (int y = 0; y < height; y++)
+                if (img[q][(size_t)y * rs] > 4) {
+                    e->err = "bad PNG filter type";
+                    return TW_E_BAD_IMAGE_FORMAT;
+                }
+        }
+    }
+    const size_t filt_need = png ? (png_rows_bytes(width, height, std::max(ch_a, ch_b)) + 255) / 256 * 256 : 0;
     TW_HIP(e, hipSetDevice(e->device));
     // host images are staged densely; device images are read in place with their own row stride
     const long long eff_stride = h_a ? (long long)width : (long long)stride;
     Ctx* c = &e->ctx[e->cur];
     // a batch is homogeneous: same size, span, threshold and row stride
     const bool open = !c->launched && !c->jobs.empty();
+    // (a filtered image larger than the slots this batch's earlier filtered images were given starts a new batch)
     const bool fits = open && c->w == width && c->h == height && c->span == span && c->threshold == threshold &&
-                      c->jobs[0].stride == eff_stride && (int)c->jobs.size() < e->cap;
+                      c->jobs[0].stride == eff_stride && (int)c->jobs.size() < e->cap &&
+                      (!png || c->filt_slot == 0 || filt_need <= c->filt_slot);
     if (!fits) {
         if (open && (r = flush_ctx(e, *c))) {
             // the open batch cannot run (unsupported plan, out of memory): drop it as tw_wait does, so that the
@@ -1437,6 +1495,8 @@ tw_status submit_common(tw_engine* e, const uint8_t* h_a, const uint8_t* h_b, co
         c->span = span;
         c->threshold = threshold;
         c->any_host = false;
+        c->any_png = false;
+        c->filt_slot = 0;
         c->first_ticket = e->next_ticket;
     }
     Job jb;
@@ -1456,6 +1516,51 @@ tw_status submit_common(tw_engine* e, const uint8_t* h_a, const uint8_t* h_b, co
         }
         uint8_t* dst_a = c->d_img + npx * (2 * j);
         uint8_t* dst_b = c->d_img + npx * (2 * j + 1);
+        if (png) {
+            // tw_submit_png8: filtered rows go to the batch's d_filt slots (tw_png_unfilter writes d_img when the batch
+            // is launched), plain gray images of the pair straight to d_img
+            if (c->filt_slot == 0) {
+                // first filtered image of this batch: slots as large as the region allows, at least what it needs
+                const size_t have = c->d_filt_cap / (2 * (size_t)e->cap) / 256 * 256;
+                c->filt_slot = std::max(filt_need, have);
+                if (c->filt_slot * 2 * (size_t)e->cap > c->d_filt_cap) {
+                    TW_HIP(e, hipStreamSynchronize(e->copy_stream));
+                    if (c->d_filt) (void)hipFree(c->d_filt);
+                    c->d_filt = nullptr;
+                    c->d_filt_cap = 0;
+                    TW_HIP(e, hipMalloc((void**)&c->d_filt, c->filt_slot * 2 * (size_t)e->cap + 256));
+                    c->d_filt_cap = c->filt_slot * 2 * (size_t)e->cap;
+                }
+            }
+            const uint8_t* src[2] = {h_a, h_b};
+            const int chs[2] = {ch_a, ch_b};
+            uint8_t* gray_dst[2] = {dst_a, dst_b};
+            for (int q = 0; q < 2; q++) {
+                const size_t nb = chs[q] ? png_rows_bytes(width, height, chs[q]) : (size_t)width * height;
+                uint8_t* dst = chs[q] ? c->d_filt + c->filt_slot * (2 * j + q) : gray_dst[q];
+                if (pin_registry().covers(src[q], nb)) {
+                    TW_HIP(e, hipMemcpyAsync(dst, src[q], nb, hipMemcpyHostToDevice, e->copy_stream));
+                    continue;
+                }
+                // pageable memory: the caller may reuse it as soon as this call returns, and the runtime is never handed
+                // a pointer it would have to page-lock on the fly — the image goes through the engine's own pinned bounce
+                // buffer and the copy is over before the next one starts (the host layer hands over page-locked arenas;
+                // this is the slow, always-correct path)
+                if (nb > e->h_bounce_cap) {
+                    if (e->h_bounce) (void)hipHostFree(e->h_bounce);
+                    e->h_bounce = nullptr;
+                    e->h_bounce_cap = 0;
+                    TW_HIP(e, hipHostMalloc((void**)&e->h_bounce, nb, hipHostMallocDefault));
+                    e->h_bounce_cap = nb;
+                }
+                memcpy(e->h_bounce, src[q], nb);
+                TW_HIP(e, hipMemcpyAsync(dst, e->h_bounce, nb, hipMemcpyHostToDevice, e->copy_stream));
+                TW_HIP(e, hipStreamSynchronize(e->copy_stream));
+            }
+            jb.png_ch[0] = ch_a;
+            jb.png_ch[1] = ch_b;
+            c->any_png = true;
+        } else {
         const size_t span_bytes = (size_t)stride * (size_t)(height - 1) + (size_t)width;
         if (pin_registry().covers(h_a, span_bytes) && pin_registry().covers(h_b, span_bytes)) {
             // page-locked caller memory (tw_host_alloc / tw_host_register): DMA straight from it.  The caller keeps
@@ -1489,6 +1594,7 @@ tw_status submit_common(tw_engine* e, const uint8_t* h_a, const uint8_t* h_b, co
             // whatever the compute stream is still doing for the previous batch
             TW_HIP(e, hipMemcpyAsync(dst_a, da, npx * 2, hipMemcpyHostToDevice, e->copy_stream));
         }
+        }  // !png
         jb.h_a = h_a;
         jb.h_b = h_b;
         c->any_host = true;
@@ -1675,6 +1781,8 @@ tw_status tw_engine_create(int device, const tw_params* params, int slots, tw_en
              hipEventCreateWithFlags(&c.ev_h2d, hipEventDisableTiming) == hipSuccess &&
              hipHostMalloc((void**)&c.h_ptrs, sizeof(void*) * 2 * slots, hipHostMallocDefault) == hipSuccess &&
              hipHostMalloc((void**)&c.h_count, sizeof(int) * slots, hipHostMallocDefault) == hipSuccess &&
+             hipHostMalloc((void**)&c.h_png, sizeof(PngJob) * 2 * (size_t)slots, hipHostMallocDefault) == hipSuccess &&
+             hipMalloc((void**)&c.d_png, sizeof(PngJob) * 2 * (size_t)slots + 256) == hipSuccess &&
              hipHostMalloc((void**)&c.h_rec, sizeof(ScanRec) * HOST_RECS * (size_t)slots, hipHostMallocDefault) ==
                  hipSuccess;
     }
@@ -1702,6 +1810,7 @@ void tw_engine_destroy(tw_engine* e)
     if (e->d_count) (void)hipFree(e->d_count);
     if (e->d_grid) (void)hipFree(e->d_grid);
     if (e->Vd) (void)hipFree(e->Vd);
+    if (e->h_bounce) (void)hipHostFree(e->h_bounce);
     if (e->dbg_stamps) (void)hipFree(e->dbg_stamps);
     if (e->lat_I) (void)hipFree(e->lat_I);
     if (e->lat_R) (void)hipFree(e->lat_R);
@@ -1710,6 +1819,9 @@ void tw_engine_destroy(tw_engine* e)
         if (c.h_img) (void)hipHostFree(c.h_img);
         if (c.d_img) (void)hipFree(c.d_img);
         if (c.d_rec) (void)hipFree(c.d_rec);
+        if (c.d_filt) (void)hipFree(c.d_filt);
+        if (c.d_png) (void)hipFree(c.d_png);
+        if (c.h_png) (void)hipHostFree(c.h_png);
         if (c.ev_h2d) (void)hipEventDestroy(c.ev_h2d);
         if (c.h_ptrs) (void)hipHostFree((void*)c.h_ptrs);
         if (c.h_count) (void)hipHostFree(c.h_count);
@@ -1738,6 +1850,15 @@ tw_status tw_submit_u8(tw_engine* e, const uint8_t* expect, const uint8_t* targe
 {
     if (!expect || !target) return TW_E_BAD_PARAMETER;
     return submit_common(e, expect, target, nullptr, nullptr, width, height, stride, span, threshold, ticket);
+}
+
+tw_status tw_submit_png8(tw_engine* e, const uint8_t* expect, int expect_channels, const uint8_t* target,
+                         int target_channels, int width, int height, int span, double threshold, tw_ticket* ticket)
+{
+    if (expect_channels == 0 && target_channels == 0)  // two plain gray images: the ordinary host path
+        return submit_common(e, expect, target, nullptr, nullptr, width, height, width, span, threshold, ticket);
+    return submit_common(e, expect, target, nullptr, nullptr, width, height, width, span, threshold, ticket,
+                         expect_channels, target_channels);
 }
 
 tw_status tw_submit_dev(tw_engine* e, const void* d_expect, const void* d_target, int width, int height,
@@ -1848,13 +1969,36 @@ tw_status tw_flow_u8(tw_engine* e, const uint8_t* expect, const uint8_t* target,
     const float* f = e->flow[0];
     // on the engine's own stream, then one host-side synchronise of it (copies on the null stream are never
     // followed by one, and this runtime keeps a little bookkeeping per command until a stream is synchronised)
-    if (flowx)
-        TW_HIP(e, hipMemcpy2DAsync(flowx, (size_t)width * 4, f, (size_t)L0.ld * 4, (size_t)width * 4, height,
-                                   hipMemcpyDeviceToHost, e->stream));
-    if (flowy)
-        TW_HIP(e, hipMemcpy2DAsync(flowy, (size_t)width * 4, f + L0.ps, (size_t)L0.ld * 4, (size_t)width * 4, height,
-                                   hipMemcpyDeviceToHost, e->stream));
+    // The planes come down into the engine's own page-locked bounce buffer and are copied out by the CPU, unless the
+    // caller's planes are page-locked blocks the library knows (tw_host_alloc / tw_host_register): the runtime is never
+    // handed a pageable pointer it would have to page-lock on the fly (round 4: a fault on a malloc-heap address inside
+    // this call, after an earlier hipHostRegister / hipHostUnregister of a neighbouring heap block).
+    const size_t plane = (size_t)width * height * 4;
+    float* dst[2] = {flowx, flowy};
+    float* via[2] = {flowx, flowy};
+    size_t need = 0;
+    for (int q = 0; q < 2; q++)
+        if (dst[q] && !pin_registry().covers(dst[q], plane)) need += plane;
+    if (need > e->h_bounce_cap) {
+        if (e->h_bounce) (void)hipHostFree(e->h_bounce);
+        e->h_bounce = nullptr;
+        e->h_bounce_cap = 0;
+        TW_HIP(e, hipHostMalloc((void**)&e->h_bounce, need, hipHostMallocDefault));
+        e->h_bounce_cap = need;
+    }
+    size_t off = 0;
+    for (int q = 0; q < 2; q++) {
+        if (!dst[q]) continue;
+        if (!pin_registry().covers(dst[q], plane)) {
+            via[q] = (float*)(e->h_bounce + off);
+            off += plane;
+        }
+        TW_HIP(e, hipMemcpy2DAsync(via[q], (size_t)width * 4, f + (q ? L0.ps : 0), (size_t)L0.ld * 4, (size_t)width * 4,
+                                   height, hipMemcpyDeviceToHost, e->stream));
+    }
     TW_HIP(e, hipStreamSynchronize(e->stream));
+    for (int q = 0; q < 2; q++)
+        if (dst[q] && via[q] != dst[q]) memcpy(dst[q], via[q], plane);
     return TW_OK;
 }
 
@@ -2256,6 +2400,46 @@ tw_status tw_stage_pyr_level(tw_engine* e, const uint8_t* img, int w0, int h0, i
     if ((r = down_planes(e, I, d_I, L.ld, L.ps, L.w, L.h, 1))) return r;
     if (w) *w = L.w;
     if (h) *h = L.h;
+    return TW_OK;
+}
+
+tw_status tw_stage_png_unfilter(tw_engine* e, const uint8_t* rows, int channels, int w, int h, int waves, uint8_t* gray)
+{
+    if (!e || !rows || !gray || channels < 1 || channels > 4) return TW_E_BAD_PARAMETER;
+    tw_status r = check_dims(e, w, h);
+    if (r) return r;
+    TW_HIP(e, hipSetDevice(e->device));
+    const size_t nb = png_rows_bytes(w, h, channels);
+    for (int y = 0; y < h; y++)
+        if (rows[(size_t)y * ((size_t)w * channels + 1)] > 4) {
+            e->err = "bad PNG filter type";
+            return TW_E_BAD_IMAGE_FORMAT;
+        }
+    if (waves == 0) waves = w <= PNG_LDS_PIXELS / 16 ? 16 : (w <= PNG_LDS_PIXELS / 4 ? 4 : 1);
+    if ((waves != 1 && waves != 4 && waves != 16) || w > PNG_LDS_PIXELS / waves) return TW_E_BAD_PARAMETER;
+    Tmp t;
+    uint8_t* d_rows = t.alloc<uint8_t>(nb);
+    uint8_t* d_gray = t.alloc<uint8_t>(staged_image_bytes(w, h));
+    PngJob* d_job = t.alloc<PngJob>(1);
+    if (!d_rows || !d_gray || !d_job) return TW_E_NOMEM;
+    TW_HIP(e, hipMemcpy(d_rows, rows, nb, hipMemcpyHostToDevice));
+    PngJob pj;
+    pj.src = d_rows;
+    pj.dst = d_gray;
+    pj.ch = channels;
+    pj.pad = 0;
+    TW_HIP(e, hipMemcpy(d_job, &pj, sizeof(pj), hipMemcpyHostToDevice));
+    PngArgs pa;
+    pa.jobs = d_job;
+    pa.w = w;
+    pa.h = h;
+    hipStream_t st = e->stream;
+    if (waves == 16) hipLaunchKernelGGL(tw_png_unfilter<16>, dim3(1), dim3(1024), 0, st, pa);
+    else if (waves == 4) hipLaunchKernelGGL(tw_png_unfilter<4>, dim3(1), dim3(256), 0, st, pa);
+    else hipLaunchKernelGGL(tw_png_unfilter<1>, dim3(1), dim3(64), 0, st, pa);
+    TW_HIP(e, hipGetLastError());
+    TW_HIP(e, hipStreamSynchronize(st));
+    TW_HIP(e, hipMemcpy(gray, d_gray, (size_t)w * h, hipMemcpyDeviceToHost));
     return TW_OK;
 }
 

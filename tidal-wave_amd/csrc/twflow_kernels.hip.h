@@ -2878,4 +2878,119 @@ __global__ __launch_bounds__(1024) void tw_span_scan(ScanArgs a)
     if (tid == 0) a.count[z] = base_out;
 }
 
+// =====================================================================================================
+// K0  tw_png_unfilter<NWV> : PNG scanline reconstruction (ISO/IEC 15948 §9: None / Sub / Up / Average / Paeth) of 8-bit
+//   gray, gray+alpha, RGB or RGBA rows + libpng-1.5 gray conversion, on the device — the part of cv::imread
+//   (src/opticalflow.cpp:37-48) that is byte arithmetic with a left / up / up-left dependence, taken off the host's
+//   decode threads.  The host inflates; the filtered rows go up as they are.
+//   One workgroup per image, one LANE per ROW, rows skewed by one pixel: at step t lane r of wave v reconstructs pixel
+//   x = t - r - (64 + S) v of its row.  Then
+//     a (left)    = the lane's own previous result
+//     b (up)      = lane r-1's previous result (DPP wave_shr:1); lane 0 reads it from the row the previous wave's lane 63
+//                   published in LDS S + 1 steps — at least one workgroup barrier — earlier; the first wave of a band
+//                   reads the last row of the previous band there
+//     c (up-left) = the lane's previous b
+//   so a wave advances 64 rows at once and NWV waves 64 NWV rows; a band of 64 NWV rows takes w + 64 NWV + S (NWV - 1)
+//   steps, one barrier every S steps.  A pixel's channels ride in the bytes of one dword.
+// =====================================================================================================
+struct PngJob {
+    const uint8_t* src;  // filtered rows: h x (1 + w * ch) bytes (filter type byte first)
+    uint8_t* dst;        // gray, w x h, dense
+    int ch;              // 1 gray, 2 gray + alpha, 3 RGB, 4 RGBA; 0: nothing to do (the image came as gray)
+    int pad;
+};
+struct PngArgs {
+    const PngJob* jobs;
+    int w, h;
+};
+constexpr int PNG_S = 64;            // steps between two workgroup barriers
+constexpr int PNG_LDS_PIXELS = 32768;  // NWV x WMAX: 128 KB of row buffers per workgroup
+
+__device__ __forceinline__ unsigned png_paeth(unsigned a, unsigned b, unsigned c)
+{
+    const int p = (int)a + (int)b - (int)c;
+    const int pa = abs(p - (int)a), pb = abs(p - (int)b), pc = abs(p - (int)c);
+    return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+}
+
+template <int NWV>
+__global__ __launch_bounds__(64 * NWV) void tw_png_unfilter(PngArgs a)
+{
+    constexpr int WMAX = PNG_LDS_PIXELS / NWV, ROWS = 64 * NWV, S = PNG_S;
+    __shared__ unsigned edge[NWV][WMAX];  // edge[v][x]: pixel x of the row lane 63 of wave v reconstructed last
+    const PngJob job = a.jobs[blockIdx.x];
+    const int ch = job.ch;  // workgroup-uniform
+    if (ch == 0) return;
+    const int w = a.w, h = a.h, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const long long stride = (long long)w * ch + 1;
+    const int off = lane + (64 + S) * wv;
+    const int steps = (w + ROWS + S * (NWV - 1) + S - 1) / S * S;
+    const bool dword_out = (w & 3) == 0;  // dst rows then start on a dword (the image slot is 256-byte aligned)
+    const int prev_wave = (wv + NWV - 1) % NWV;
+    for (int band = 0; band * ROWS < h; band++) {
+        const int row = band * ROWS + tid;
+        const bool active = row < h;
+        const uint8_t* __restrict__ in = job.src + (long long)(active ? row : 0) * stride;
+        uint8_t* __restrict__ out = job.dst + (long long)(active ? row : 0) * w;
+        unsigned ft = active ? in[0] : 0u;
+        if (ft > 4u) ft = 0u;  // (the host refuses such files before they get here)
+        const bool has_up = row > 0;
+        unsigned cur = 0, bprev = 0, acc = 0;
+        for (int t0 = 0; t0 < steps; t0 += S) {
+#pragma unroll 4
+            for (int t = t0; t < t0 + S; t++) {
+                const int x = t - off;
+                const bool on = active && x >= 0 && x < w;
+                // up: the row above finished pixel x one step ago
+                unsigned b = dpp_from_prev(cur);
+                if (lane == 0) b = (has_up && on) ? edge[prev_wave][x] : 0u;
+                if (!has_up) b = 0u;
+                const unsigned left = x > 0 ? cur : 0u, c = x > 0 ? bprev : 0u;
+                unsigned raw = 0;
+                if (on) {
+                    const uint8_t* q = in + 1 + (long long)x * ch;
+                    raw = q[0];
+                    if (ch >= 2) raw |= (unsigned)q[1] << 8;
+                    if (ch >= 3) raw |= (unsigned)q[2] << 16;
+                    if (ch >= 4) raw |= (unsigned)q[3] << 24;
+                }
+                unsigned rec = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    if (k < ch) {
+                        const unsigned av = (left >> (8 * k)) & 255u, bv = (b >> (8 * k)) & 255u, cv = (c >> (8 * k)) & 255u;
+                        unsigned pred = 0;
+                        if (ft == 1u) pred = av;
+                        else if (ft == 2u) pred = bv;
+                        else if (ft == 3u) pred = (av + bv) >> 1;
+                        else if (ft == 4u) pred = png_paeth(av, bv, cv);
+                        rec |= ((((raw >> (8 * k)) & 255u) + pred) & 255u) << (8 * k);
+                    }
+                }
+                if (on) {
+                    cur = rec;
+                    bprev = b;
+                    if (lane == 63) edge[wv][x] = rec;
+                    // libpng 1.5.12 png_do_rgb_to_gray as OpenCV 2.4.9 configures it: truncated 15-bit coefficients
+                    unsigned g = rec & 255u;
+                    if (ch >= 3) {
+                        const unsigned gg = (rec >> 8) & 255u, bb = (rec >> 16) & 255u;
+                        if (!(g == gg && gg == bb)) g = (9797u * g + 19234u * gg + 3737u * bb) >> 15;
+                    }
+                    if (dword_out) {
+                        acc |= g << (8 * (x & 3));
+                        if ((x & 3) == 3) {
+                            *(unsigned*)(out + x - 3) = acc;
+                            acc = 0;
+                        }
+                    } else {
+                        out[x] = (uint8_t)g;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
 }  // namespace twk

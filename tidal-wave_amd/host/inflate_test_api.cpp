@@ -40,6 +40,24 @@ int twt_load_gray(const char* path, uint8_t* out, size_t cap, int* w, int* h)
     memcpy(out, img.data(), img.size() < cap ? img.size() : cap);
     return 1;
 }
+// load_gray_or_png_rows(path, want_rows = true): 1 + w, h, ch and the first min(cap, size) bytes (ch = 0: gray pixels;
+// ch 1-4: filtered PNG rows); *size = the full byte count
+int twt_load_rows(const char* path, uint8_t* out, size_t cap, int* w, int* h, int* ch, size_t* size)
+{
+    std::vector<uint8_t> img;
+    if (!twhost::load_gray_or_png_rows(path, true, img, *w, *h, *ch)) return 0;
+    *size = img.size();
+    memcpy(out, img.data(), img.size() < cap ? img.size() : cap);
+    return 1;
+}
+// finish_png_rows_on_host: rows -> gray (w * h bytes into out)
+int twt_finish_rows(const uint8_t* rows, size_t n, int w, int h, int ch, uint8_t* out)
+{
+    std::vector<uint8_t> r(rows, rows + n), g;
+    if (!twhost::finish_png_rows_on_host(r, w, h, ch, g) || g.size() != (size_t)w * h) return 0;
+    memcpy(out, g.data(), g.size());
+    return 1;
+}
 // the same inflate-heavy loop a mutation fuzzer wants, inside the sanitised library: `iters` mutations of one zlib
 // stream, each decoded into a buffer of exactly `cap` bytes; returns how many were accepted
 long twt_fuzz_stream(const uint8_t* s, size_t n, size_t cap, int iters, unsigned seed)

@@ -98,6 +98,12 @@ tw_status tw_submit_u8(tw_engine* e, const uint8_t* a, const uint8_t* b, int w, 
     e->open[*t] = w + (a[0] != b[0] ? 1000000 : 0);
     return TW_OK;
 }
+tw_status tw_submit_png8(tw_engine* e, const uint8_t* a, int cha, const uint8_t* b, int chb, int w, int h, int span, double thr,
+                         tw_ticket* t)
+{
+    // filtered rows: byte 0 is a filter type, byte 1 the first sample — compare those like tw_submit_u8 compares pixel 0
+    return tw_submit_u8(e, a + (cha ? 1 : 0), b + (chb ? 1 : 0), w, h, w, span, thr, t);
+}
 tw_status tw_flush(tw_engine*) { return TW_OK; }
 tw_status tw_wait(tw_engine* e, tw_ticket t, tw_vector* out, int cap, int* n, float* seconds)
 {

@@ -327,13 +327,27 @@ static uint32_t png_crc32(const uint8_t* p, size_t n)
     return c ^ 0xFFFFFFFFu;
 }
 
-static bool decode_png(const std::vector<uint8_t>& d, std::vector<uint8_t>& img, int& w, int& h)
+// What is left of a PNG after its chunks are parsed and its IDAT stream is inflated: the filtered scanlines (one pass,
+// or the seven Adam7 passes one after the other) and what is needed to finish them
+struct PngStream {
+    std::unique_ptr<uint8_t[]> raw;  // `total` bytes of filtered rows (+ 8 bytes of slack)
+    size_t total = 0;
+    int w = 0, h = 0, depth = 0, ctype = 0, interlace = 0, ch = 0;
+    std::vector<uint8_t> plte;
+    // 8-bit, not interlaced, gray / gray + alpha / RGB / RGBA: rows the device reconstructs (tw_submit_png8)
+    bool device_rows() const { return depth == 8 && !interlace && ctype != 3; }
+};
+
+// stage 1 of cv::imread on a PNG: chunk walk (libpng's rules) + inflate
+static bool png_parse_inflate(const std::vector<uint8_t>& d, PngStream& ps)
 {
+    int w = 0, h = 0;
     static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
     if (d.size() < 33 || memcmp(d.data(), sig, 8) != 0) return false;
     size_t p = 8;
     int depth = 0, ctype = 0, interlace = 0;
-    std::vector<uint8_t> idat, plte;
+    std::vector<uint8_t> idat;
+    std::vector<uint8_t>& plte = ps.plte;
     bool have_ihdr = false, idat_done = false, first = true;
     // Chunk rules the way libpng (cv::imread) enforces them — a file it refuses answers "Can't open" here as well
     // (ADVICE r3): IHDR first; the CRC of every CRITICAL chunk (IHDR, PLTE, IDAT; an upper-case first letter) must
@@ -382,7 +396,6 @@ static bool decode_png(const std::vector<uint8_t>& d, std::vector<uint8_t>& img,
     if (!(depth == 8 || depth == 16 || ((ctype == 0 || ctype == 3) && (depth == 1 || depth == 2 || depth == 4))))
         return false;
     const size_t bpp_bits = (size_t)ch * depth;
-    const size_t fbpp = std::max<size_t>(1, bpp_bits / 8);
     // Adam7 (interlace 1): seven reduced images one after the other, each with its own filtered rows; a pass is
     // unfiltered and converted like a whole image and its pixels scattered to (x0 + i*dx, y0 + j*dy)
     static const int AX0[7] = {0, 4, 0, 2, 0, 1, 0}, AY0[7] = {0, 0, 4, 0, 2, 0, 1};
@@ -399,11 +412,33 @@ static bool decode_png(const std::vector<uint8_t>& d, std::vector<uint8_t>& img,
     // DEFLATE expands by at most 1032 : 1: a stream too short for the image the header announces is refused before
     // `total` bytes (up to 8 GiB for 32768 x 32768 RGBA16) are allocated for it
     if (total / 1032 > idat.size()) return false;
-    std::unique_ptr<uint8_t[]> raw_buf(new (std::nothrow) uint8_t[total + 8]);
-    if (!raw_buf) return false;
-    uint8_t* const raw = raw_buf.get();
+    ps.raw.reset(new (std::nothrow) uint8_t[total + 8]);
+    if (!ps.raw) return false;
+    uint8_t* const raw = ps.raw.get();
+    ps.total = total;
+    ps.w = w;
+    ps.h = h;
+    ps.depth = depth;
+    ps.ctype = ctype;
+    ps.interlace = interlace;
+    ps.ch = ch;
     size_t outlen = 0;
     if (!tw_inflate_zlib(idat.data(), idat.size(), raw, total, &outlen) || outlen != total) return false;
+    return true;
+}
+
+// stage 2: scanline reconstruction (tw_inflate.cpp) + conversion to 8-bit gray with libpng 1.5's formula — on the host
+// (every PNG kind; what tw_png_unfilter does on the device for the 8-bit non-interlaced kinds)
+static bool png_finish_on_host(PngStream& st, std::vector<uint8_t>& img)
+{
+    uint8_t* const raw = st.raw.get();
+    const int w = st.w, h = st.h, depth = st.depth, ctype = st.ctype, interlace = st.interlace, ch = st.ch;
+    const std::vector<uint8_t>& plte = st.plte;
+    const size_t bpp_bits = (size_t)ch * depth;
+    const size_t fbpp = std::max<size_t>(1, bpp_bits / 8);
+    static const int AX0[7] = {0, 4, 0, 2, 0, 1, 0}, AY0[7] = {0, 0, 4, 0, 2, 0, 1};
+    static const int ADX[7] = {8, 8, 4, 4, 2, 2, 1}, ADY[7] = {8, 8, 8, 4, 4, 2, 2};
+    const int npass = interlace ? 7 : 1;
     img.resize((size_t)w * h);
     size_t pass_off = 0;
     const int W = w, H = h;  // the loops below run over one pass: w/h are its dimensions
@@ -453,26 +488,78 @@ static bool decode_png(const std::vector<uint8_t>& d, std::vector<uint8_t>& img,
     }
     pass_off += (rowbytes + 1) * (size_t)h;
     }
-    w = W;
-    h = H;
     return true;
+}
+
+static bool decode_png(const std::vector<uint8_t>& d, std::vector<uint8_t>& img, int& w, int& h)
+{
+    PngStream st;
+    if (!png_parse_inflate(d, st)) return false;
+    w = st.w;
+    h = st.h;
+    return png_finish_on_host(st, img);
+}
+
+// The rest of the decode of rows load_gray_or_png_rows() returned (size reconcile needs gray pixels on the host)
+bool finish_png_rows_on_host(std::vector<uint8_t>& rows, int w, int h, int ch, std::vector<uint8_t>& gray)
+{
+    if (ch < 1 || ch > 4 || rows.size() != (size_t)h * ((size_t)w * ch + 1)) return false;
+    PngStream st;
+    st.total = rows.size();
+    st.raw.reset(new (std::nothrow) uint8_t[st.total + 8]);
+    if (!st.raw) return false;
+    memcpy(st.raw.get(), rows.data(), st.total);
+    st.w = w;
+    st.h = h;
+    st.depth = 8;
+    st.interlace = 0;
+    st.ch = ch;
+    st.ctype = ch == 1 ? 0 : ch == 2 ? 4 : ch == 3 ? 2 : 6;
+    return png_finish_on_host(st, gray);
 }
 
 bool load_gray(const std::string& path, std::vector<uint8_t>& img, int& w, int& h)
 {
+    int ch = 0;
+    return load_gray_or_png_rows(path, false, img, w, h, ch);
+}
+
+// cv::imread(path, GRAYSCALE) — or, with want_rows and an 8-bit non-interlaced gray / gray + alpha / RGB / RGBA PNG,
+// only its first half: `img` then holds the inflated, still FILTERED scanlines (h rows of 1 + w * ch bytes) and ch is
+// 1-4; the device finishes them (tw_submit_png8).  Every row's filter type is checked here (0-4, as libpng does).
+// ch = 0: `img` is the gray image.
+bool load_gray_or_png_rows(const std::string& path, bool want_rows, std::vector<uint8_t>& img, int& w, int& h, int& ch)
+{
     std::vector<uint8_t> d;
-    w = h = 0;
+    w = h = ch = 0;
     if (!read_file(path, d) || d.size() < 8) return false;
     bool ok = false;
     if (d[0] == 'P' && d[1] >= '1' && d[1] <= '6') ok = decode_pnm(d, img, w, h);
-    else if (d[0] == 0x89 && d[1] == 'P') ok = decode_png(d, img, w, h);
+    else if (d[0] == 0x89 && d[1] == 'P' && want_rows) {
+        PngStream st;
+        ok = png_parse_inflate(d, st);
+        if (ok) {
+            w = st.w;
+            h = st.h;
+            if (st.device_rows()) {
+                const size_t rs = (size_t)st.w * st.ch + 1;
+                for (int y = 0; y < st.h && ok; y++) ok = st.raw[(size_t)y * rs] <= 4;
+                if (ok) {
+                    img.assign(st.raw.get(), st.raw.get() + st.total);
+                    ch = st.ch;
+                }
+            } else {
+                ok = png_finish_on_host(st, img);
+            }
+        }
+    } else if (d[0] == 0x89 && d[1] == 'P') ok = decode_png(d, img, w, h);
     else if (d[0] == 0xFF && d[1] == 0xD8) ok = decode_jpeg_gray(d.data(), d.size(), img, w, h);
     else if (d[0] == 'B' && d[1] == 'M') ok = decode_bmp(d, img, w, h);
     // (the other cv::imread formats — TIFF, JPEG-2000, Sun raster, ... — are not decoded: INTEGRATION.md)
     if (!ok) {
         // the decoders write w / h from the header before they can fail: a failed decode reports no size (ADVICE r3:
         // a 32768 x 32768 IHDR over a truncated IDAT used to size the page-locked arena)
-        w = h = 0;
+        w = h = ch = 0;
         std::vector<uint8_t>().swap(img);
     }
     return ok;
@@ -553,6 +640,7 @@ struct Staged {
     const uint8_t *pa = nullptr, *pb = nullptr;  // the pair as handed to the engine (a/b or the caller's raw buffers)
     ptrdiff_t stride = 0;
     int w = 0, h = 0;
+    int cha = 0, chb = 0;  // > 0: a / b hold filtered PNG rows of that many channels (the device finishes them)
     std::string err;
     tw_ticket ticket = 0;
     bool submitted = false;
@@ -560,15 +648,15 @@ struct Staged {
 };
 
 // the two imreads of a pair are independent: the decode pool runs them as separate tasks (task = 2 * job + image)
-void decode_one(Staged& s, int which, int* tw, int* th, std::string* err)
+void decode_one(Staged& s, int which, int* tw, int* th, std::string* err, bool device_png)
 {
     if (s.req.raw.expect) return;
     if (which == 0) {
         if (s.req.expect_image.empty()) { *err = "ExpectImagePath is empty."; return; }
-        if (!load_gray(s.req.expect_image, s.a, s.w, s.h)) *err = "Can't open " + s.req.expect_image;
+        if (!load_gray_or_png_rows(s.req.expect_image, device_png, s.a, s.w, s.h, s.cha)) *err = "Can't open " + s.req.expect_image;
     } else {
         if (s.req.target_image.empty()) { *err = "TargetImagePath is empty."; return; }
-        if (!load_gray(s.req.target_image, s.b, *tw, *th)) *err = "Can't open " + s.req.target_image;
+        if (!load_gray_or_png_rows(s.req.target_image, device_png, s.b, *tw, *th, s.chb)) *err = "Can't open " + s.req.target_image;
     }
 }
 
@@ -592,6 +680,14 @@ void prepare(Staged& s, int tw, int th, const std::string& err_a, const std::str
     if (!err_b.empty()) { s.err = err_b; return; }
     if (abs(s.h - th) > 5 || abs(s.w - tw) > 5) { s.err = "Don't match image size"; return; }
     if (s.h != th || s.w != tw) {
+        // the <= 5 px reconcile resizes the TARGET's gray pixels (src/opticalflow.cpp:64-68): a target that is still
+        // filtered PNG rows is finished on the host first (rare; the expected image may stay as it is)
+        if (s.chb) {
+            std::vector<uint8_t> g;
+            if (!finish_png_rows_on_host(s.b, tw, th, s.chb, g)) { s.err = "Can't open " + s.req.target_image; return; }
+            s.b.swap(g);
+            s.chb = 0;
+        }
         std::vector<uint8_t> r;
         resize_u8_linear(s.b, tw, th, r, s.w, s.h);
         s.b.swap(r);
@@ -623,6 +719,10 @@ void Consumer::run()
             mine.numaNode = node;
         mine.cpus = this_thread_cpus();
     }
+    // PNG scanline reconstruction + gray conversion on the device (tw_submit_png8): the decode pool only inflates.
+    // TW_DEVICE_PNG=0 keeps the whole decode on the host (A/B switch; same bytes either way).
+    bool device_png = true;
+    if (const char* ev = getenv("TW_DEVICE_PNG")) device_png = atoi(ev) != 0;
     tw_engine* eng = nullptr;
     std::string eng_err;
     if (ndev > 0) {
@@ -764,7 +864,7 @@ void Consumer::run()
             };
             parallel_for(2 * jobs.size(), [&](size_t i) {
                 const size_t j = i >> 1;
-                decode_one(jobs[j], (int)(i & 1), &tw[j], &th[j], (i & 1) ? &eb[j] : &ea[j]);
+                decode_one(jobs[j], (int)(i & 1), &tw[j], &th[j], (i & 1) ? &eb[j] : &ea[j], device_png);
             });
             // Second pass, still in the pool: size reconcile, then the pair moves into this batch's page-locked arena,
             // so that tw_submit_u8 DMAs straight from it.  Round 3: with the decode itself 2.6x faster, the staging
@@ -781,7 +881,8 @@ void Consumer::run()
             size_t slot = 0;
             for (const Staged& s : jobs) {
                 if (!s.err.empty() || s.req.raw.expect) continue;
-                const size_t nb = ((size_t)s.w * s.h + 255) / 256 * 256;
+                // (an image is w * h gray bytes or, still filtered, h * (1 + w * ch) bytes)
+                const size_t nb = (std::max(s.a.size(), s.b.size()) + 255) / 256 * 256;
                 if (nb <= kArenaSlotMax) slot = std::max(slot, nb);
             }
             Arena& ar = arena[arena_idx];
@@ -802,12 +903,11 @@ void Consumer::run()
             parallel_for(jobs.size(), [&](size_t j) {
                 Staged& s = jobs[j];
                 if (!s.err.empty() || s.req.raw.expect || !ar.base || !slot) return;
-                const size_t nb = (size_t)s.w * s.h;
-                if (nb > slot || (2 * j + 2) * slot > ar.cap) return;  // stays pageable
+                if (std::max(s.a.size(), s.b.size()) > slot || (2 * j + 2) * slot > ar.cap) return;  // stays pageable
                 uint8_t* da = ar.base + slot * (2 * j);
                 uint8_t* db = da + slot;
-                memcpy(da, s.a.data(), nb);
-                memcpy(db, s.b.data(), nb);
+                memcpy(da, s.a.data(), s.a.size());
+                memcpy(db, s.b.data(), s.b.size());
                 s.pa = da;
                 s.pb = db;
                 std::vector<uint8_t>().swap(s.a);
@@ -823,13 +923,18 @@ void Consumer::run()
             Staged& s = jobs[k];
             if (s.err.empty() && !eng) s.err = eng_err;
             if (!s.err.empty()) continue;
-            tw_status r = tw_submit_u8(eng, s.pa, s.pb, s.w, s.h, s.stride, s.req.span, s.req.threshold, &s.ticket);
+            auto submit = [&]() -> tw_status {
+                if (s.cha || s.chb)  // half-decoded PNG(s): the device reconstructs the scanlines
+                    return tw_submit_png8(eng, s.pa, s.cha, s.pb, s.chb, s.w, s.h, s.req.span, s.req.threshold, &s.ticket);
+                return tw_submit_u8(eng, s.pa, s.pb, s.w, s.h, s.stride, s.req.span, s.req.threshold, &s.ticket);
+            };
+            tw_status r = submit();
             if (r == TW_E_BUSY) {
                 // every batch context of the engine is owed to us (each size change opens one): collect what
                 // is outstanding, then this job starts a fresh batch
                 finish_all(prev);
                 for (size_t q = 0; q < k; q++) finish(jobs[q]);
-                r = tw_submit_u8(eng, s.pa, s.pb, s.w, s.h, s.stride, s.req.span, s.req.threshold, &s.ticket);
+                r = submit();
             }
             if (r == TW_OK) s.submitted = true;
             else s.err = std::string(tw_last_error(eng)[0] ? tw_last_error(eng) : tw_strerror(r));

@@ -153,6 +153,10 @@ bool decode_jpeg_gray(const uint8_t* data, size_t n, std::vector<uint8_t>& img, 
 // 8-bit gray decode of a file: PGM (P5), PNG (zlib inflate + unfilter, libpng-1.5 gray conversion) and JPEG.
 // Returns false if the file cannot be opened / decoded ("Can't open <path>", src/opticalflow.cpp:40,47).
 bool load_gray(const std::string& path, std::vector<uint8_t>& img, int& w, int& h);
+// load_gray, or — want_rows and an 8-bit non-interlaced non-palette PNG — the inflated but still filtered scanlines
+// (ch 1-4: h rows of 1 + w * ch bytes for tw_submit_png8; ch 0: `img` is the gray image)
+bool load_gray_or_png_rows(const std::string& path, bool want_rows, std::vector<uint8_t>& img, int& w, int& h, int& ch);
+bool finish_png_rows_on_host(std::vector<uint8_t>& rows, int w, int h, int ch, std::vector<uint8_t>& gray);
 // cv::resize(8-bit, INTER_LINEAR) — the "<= 5 px" reconcile of src/opticalflow.cpp:64-68.
 void resize_u8_linear(const std::vector<uint8_t>& src, int sw, int sh, std::vector<uint8_t>& dst, int dw, int dh);
 

@@ -49,11 +49,11 @@ OPT_POLYEXP_F32 = 2
 
 SYMBOLS = [
     "tw_default_params", "tw_has_variants", "tw_device_count", "tw_device_pci_bus_id", "tw_engine_create", "tw_engine_destroy", "tw_strerror",
-    "tw_last_error", "tw_flow_u8", "tw_diff_u8", "tw_submit_u8", "tw_submit_dev", "tw_flush", "tw_wait",
+    "tw_last_error", "tw_flow_u8", "tw_diff_u8", "tw_submit_u8", "tw_submit_png8", "tw_submit_dev", "tw_flush", "tw_wait",
     "tw_grid_capacity", "tw_dev_alloc", "tw_dev_free", "tw_dev_upload", "tw_host_alloc", "tw_host_free", "tw_host_register", "tw_host_unregister", "tw_set_option",
     "tw_prof_select", "tw_prof_read",
     "tw_algorithmic_bytes", "tw_algorithmic_bytes_pair", "tw_min_traffic_bytes_pair", "tw_num_levels", "tw_level_chunk", "tw_bench_stage", "tw_stage_pyr_level",
-    "tw_stage_polyexp", "tw_stage_update_matrices", "tw_stage_flow_upsample_update", "tw_stage_blur_solve",
+    "tw_stage_png_unfilter", "tw_stage_polyexp", "tw_stage_update_matrices", "tw_stage_flow_upsample_update", "tw_stage_blur_solve",
 ]
 
 
@@ -116,6 +116,8 @@ def _bind(path):
                              C.POINTER(Vector), C.c_int, ip, fp]
     L.tw_submit_u8.argtypes = [vp, u8p, u8p, C.c_int, C.c_int, C.c_ssize_t, C.c_int, C.c_double,
                                C.POINTER(C.c_int64)]
+    L.tw_submit_png8.argtypes = [vp, u8p, C.c_int, u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_int64)]
+    L.tw_stage_png_unfilter.argtypes = [vp, u8p, C.c_int, C.c_int, C.c_int, C.c_int, u8p]
     L.tw_submit_dev.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_ssize_t, C.c_int, C.c_double,
                                 C.POINTER(C.c_int64)]
     L.tw_wait.argtypes = [vp, C.c_int64, C.POINTER(Vector), C.c_int, ip, fp]
@@ -274,6 +276,22 @@ class Engine:
         tk = C.c_int64()
         self._check(self._L.tw_submit_u8(self._h, p_expect, p_target, w, h, stride, span, threshold, C.byref(tk)))
         return (tk.value, w, h, span, threshold)
+
+    def submit_png8(self, expect, ch_a, target, ch_b, w, h, span=10, threshold=5.0):
+        """tw_submit_png8: each image is either filtered PNG rows (uint8 array of h * (1 + w * ch) bytes, ch 1-4) or a
+        plain gray image (ch 0, shape (h, w))."""
+        a = np.ascontiguousarray(expect, np.uint8)
+        b = np.ascontiguousarray(target, np.uint8)
+        tk = C.c_int64()
+        self._check(self._L.tw_submit_png8(self._h, _u8(a), ch_a, _u8(b), ch_b, w, h, span, threshold, C.byref(tk)))
+        return (tk.value, w, h, span, threshold)
+
+    def stage_png_unfilter(self, rows, ch, w, h, waves=0):
+        rows = np.ascontiguousarray(rows, np.uint8)
+        assert rows.size == h * (1 + w * ch)
+        out = np.empty((h, w), np.uint8)
+        self._check(self._L.tw_stage_png_unfilter(self._h, _u8(rows), ch, w, h, waves, _u8(out)))
+        return out
 
     def submit_dev(self, d_expect, d_target, w, h, stride, span=10, threshold=5.0):
         tk = C.c_int64()

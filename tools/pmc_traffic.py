@@ -9,7 +9,9 @@ import collections
 import csv
 import glob
 import json
+import os
 import sys
+import time
 
 NAMES = {"tw_blur_solve": "tw_blur_solve", "tw_polyexp": "tw_polyexp", "tw_update_matrices": "tw_update_matrices",
          "tw_pyr_k3<0>": "tw_pyr_level", "tw_span_scan": "tw_span_scan"}
@@ -44,6 +46,13 @@ def main():
             big = max(cand, key=lambda r: (r[1], r[2]))  # the largest level-0 launch (a whole engine batch)
             out[name] = {"bytes_per_launch": round(big[3] + big[4]), "pairs_per_launch": big[1] // per_pair[name],
                          "read_bytes": round(big[3]), "write_bytes": round(big[4])}
+    # where the figures come from (bench.py reads this file as a static input, so it says when and on what
+    # code it was measured).  TW_GIT_COMMIT: the GPU box has no .git; the job script passes the commit it was cut from.
+    out["_provenance"] = {"measured_utc": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime()),
+                          "commit": os.environ.get("TW_GIT_COMMIT", "unknown"),
+                          "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 "
+                                     "bench.py --steps 1 --warmup 1 --batch 128 --no-cpu-baseline --no-prof --no-extras "
+                                     "(tools/final_profile.sh)"}
     json.dump(out, open(sys.argv[3], "w"), indent=1)
     if len(sys.argv) > 4:
         with open(sys.argv[4], "w") as f:
