@@ -29,13 +29,26 @@ def write_pgm(path, img):
         f.write(np.ascontiguousarray(img).tobytes())
 
 
-def test_host_layer_under_thread_sanitizer():
+def test_host_layer_under_thread_sanitizer(tmp_path):
     if shutil.which("g++") is None:
         pytest.skip("no g++")
     r = subprocess.run(["make", "-s", "-C", HOST, "tsan"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
+    # PNG files for the decode pool's two paths (round 4: half-decoded PNGs inflate straight into the page-locked arena)
+    from PIL import Image
+    rng = np.random.default_rng(8)
+    e = rng.integers(0, 256, (90, 130, 3), dtype=np.uint8)
+    t = e.copy()
+    t[0, 0] ^= 0x55
+    Image.fromarray(e).save(tmp_path / "e.png")
+    Image.fromarray(t).save(tmp_path / "t.png")
+    Image.fromarray(t[:, :127]).save(tmp_path / "t5.png")
+    Image.fromarray(t[..., 0]).convert("P").save(tmp_path / "pal.png")
+    bad = bytearray((tmp_path / "t.png").read_bytes())
+    bad[len(bad) // 2] ^= 0x10
+    (tmp_path / "bad.png").write_bytes(bytes(bad))
     env = dict(os.environ, TSAN_OPTIONS="halt_on_error=0 exitcode=66")
-    r = subprocess.run([os.path.join(HOST, "build", "tsan_queue")], capture_output=True, text=True, timeout=600, env=env)
+    r = subprocess.run([os.path.join(HOST, "build", "tsan_queue"), str(tmp_path)], capture_output=True, text=True, timeout=600, env=env)
     assert "ThreadSanitizer" not in r.stderr, r.stderr[-4000:]
     assert r.returncode == 0, r.stdout + r.stderr[-2000:]
     assert "tsan driver: ok" in r.stdout

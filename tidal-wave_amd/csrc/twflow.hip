@@ -268,11 +268,12 @@ struct Ctx {
     hipEvent_t ev_h2d = nullptr;
     // tw_submit_png8: filtered PNG rows of the batch (2 slots of filt_slot bytes per job) and the job table of
     // tw_png_unfilter, which reconstructs them into d_img on the copy stream before ev_h2d
-    uint8_t* d_filt = nullptr;
+    uint8_t *d_filt = nullptr, *d_filt_raw = nullptr;  // d_filt = d_filt_raw + 256 (slack on both sides)
     size_t d_filt_cap = 0, filt_slot = 0;  // filt_slot: bytes per image of the open batch (0: no filtered image yet)
     PngJob* d_png = nullptr;
     PngJob* h_png = nullptr;  // pinned, [2*cap]
     bool any_png = false;
+    long long copy_ops_at_flush = 0;  // tw_engine::copy_ops when this batch was launched
     // ordered hit records of the batch [cap][G]: tw_wait reads them late when a pair has more than HOST_RECS hits,
     // so they belong to the context, not to the engine (a later batch must not overwrite them)
     ScanRec* d_rec = nullptr;
@@ -360,6 +361,8 @@ struct tw_engine {
     int win_m = 15;
     int box = 0;           // flags without 256: box window (FarnebackUpdateFlow_Blur), scan kernels
     double* Vd = nullptr;  // running column sums of the box window (5 double planes per pair of a chunk)
+    int copy_sync_skipped = 0;    // batches since the host last synchronised the copy stream (tw_wait)
+    long long copy_ops = 0;       // host images queued on the copy stream so far
     uint8_t* h_bounce = nullptr;  // pinned bounce buffer of tw_submit_png8's pageable inputs
     size_t h_bounce_cap = 0;
     size_t Vd_cap = 0;
@@ -1146,6 +1149,7 @@ tw_status flush_ctx(tw_engine* e, Ctx& c)
         else if (c.w <= PNG_LDS_PIXELS / 4) hipLaunchKernelGGL(tw_png_unfilter<4>, dim3(2 * n), dim3(256), 0, e->copy_stream, pa);
         else hipLaunchKernelGGL(tw_png_unfilter<1>, dim3(2 * n), dim3(64), 0, e->copy_stream, pa);
     }
+    c.copy_ops_at_flush = e->copy_ops;
     if (c.any_host) {
         // the uploads were queued on the copy stream as the jobs came in (submit_common)
         TW_HIP(e, hipEventRecord(c.ev_h2d, e->copy_stream));
@@ -1525,10 +1529,13 @@ tw_status submit_common(tw_engine* e, const uint8_t* h_a, const uint8_t* h_b, co
                 c->filt_slot = std::max(filt_need, have);
                 if (c->filt_slot * 2 * (size_t)e->cap > c->d_filt_cap) {
                     TW_HIP(e, hipStreamSynchronize(e->copy_stream));
-                    if (c->d_filt) (void)hipFree(c->d_filt);
-                    c->d_filt = nullptr;
+                    if (c->d_filt_raw) (void)hipFree(c->d_filt_raw);
+                    c->d_filt = c->d_filt_raw = nullptr;
                     c->d_filt_cap = 0;
-                    TW_HIP(e, hipMalloc((void**)&c->d_filt, c->filt_slot * 2 * (size_t)e->cap + 256));
+                    // 256 bytes of slack on either side: tw_png_unfilter fetches whole 16-byte groups and may read a few
+                    // bytes before the first and after the last row of an image
+                    TW_HIP(e, hipMalloc((void**)&c->d_filt_raw, c->filt_slot * 2 * (size_t)e->cap + 512));
+                    c->d_filt = c->d_filt_raw + 256;
                     c->d_filt_cap = c->filt_slot * 2 * (size_t)e->cap;
                 }
             }
@@ -1598,6 +1605,7 @@ tw_status submit_common(tw_engine* e, const uint8_t* h_a, const uint8_t* h_b, co
         jb.h_a = h_a;
         jb.h_b = h_b;
         c->any_host = true;
+        e->copy_ops++;
     } else {
         jb.d_a = (const uint8_t*)d_a;
         jb.d_b = (const uint8_t*)d_b;
@@ -1819,7 +1827,7 @@ void tw_engine_destroy(tw_engine* e)
         if (c.h_img) (void)hipHostFree(c.h_img);
         if (c.d_img) (void)hipFree(c.d_img);
         if (c.d_rec) (void)hipFree(c.d_rec);
-        if (c.d_filt) (void)hipFree(c.d_filt);
+        if (c.d_filt_raw) (void)hipFree(c.d_filt_raw);
         if (c.d_png) (void)hipFree(c.d_png);
         if (c.h_png) (void)hipHostFree(c.h_png);
         if (c.ev_h2d) (void)hipEventDestroy(c.ev_h2d);
@@ -1899,7 +1907,14 @@ tw_status tw_wait(tw_engine* e, tw_ticket ticket, tw_vector* out, int cap, int* 
         // a host-side hipStreamSynchronize: without it the process grew by ~1 KB per uploaded image (found by a
         // 300 000-pair soak; an event wait or a stream query does not release it).  The uploads it waits for are this
         // batch's (long done) and, at most, the next batch's, which that batch needs before it can start anyway.
-        (void)hipStreamSynchronize(e->copy_stream);
+        // Round 4: a caller that keeps two batches in flight has the NEXT batches' uploads (and their scanline
+        // reconstruction) queued there — 4-6 ms of waiting per batch for nothing.  So: synchronise when the stream is
+        // idle anyway (free), and otherwise only every 16th batch (the bookkeeping stays bounded at ~1 MB).
+        // (the engine counts what it queues there itself: a hipStreamQuery per batch leaves bookkeeping of its own behind)
+        if (e->copy_ops == c->copy_ops_at_flush || ++e->copy_sync_skipped >= 16) {
+            (void)hipStreamSynchronize(e->copy_stream);
+            e->copy_sync_skipped = 0;
+        }
     }
     c->jobs[j].waited = true;
     c->pending--;
@@ -2418,7 +2433,8 @@ tw_status tw_stage_png_unfilter(tw_engine* e, const uint8_t* rows, int channels,
     if (waves == 0) waves = w <= PNG_LDS_PIXELS / 16 ? 16 : (w <= PNG_LDS_PIXELS / 4 ? 4 : 1);
     if ((waves != 1 && waves != 4 && waves != 16) || w > PNG_LDS_PIXELS / waves) return TW_E_BAD_PARAMETER;
     Tmp t;
-    uint8_t* d_rows = t.alloc<uint8_t>(nb);
+    uint8_t* d_rows_raw = t.alloc<uint8_t>(nb + 512);  // the kernel may read a few bytes before / after the rows
+    uint8_t* d_rows = d_rows_raw ? d_rows_raw + 256 : nullptr;
     uint8_t* d_gray = t.alloc<uint8_t>(staged_image_bytes(w, h));
     PngJob* d_job = t.alloc<PngJob>(1);
     if (!d_rows || !d_gray || !d_job) return TW_E_NOMEM;

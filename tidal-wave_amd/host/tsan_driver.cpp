@@ -8,6 +8,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <mutex>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -46,7 +47,7 @@ static Observer observer(Sink& s)
     return o;
 }
 
-int main()
+int main(int argc, char** argv)
 {
     std::vector<uint8_t> a(64 * 48, 10), b(64 * 48, 10), c(64 * 48, 99);
     Parameter p;
@@ -127,6 +128,44 @@ int main()
         }
         delete mg;
         if (s.rep.requestCount != 4000 || s.data > 4000) { fprintf(stderr, "dispose: report %d, data %ld\n", s.rep.requestCount, s.data); rc = 1; }
+    }
+    if (argc > 1) {
+        // FILES through the decode pool (round 4): argv[1] holds e.png / t.png (same size, first pixel differs), t5.png
+        // (3 px narrower: the size-reconcile path), pal.png (palette: decoded on the host) and bad.png (damaged).  Batches
+        // of pairs the device can finish are inflated straight into the page-locked arena (the fast path); a batch with
+        // any other pair takes the decode-then-copy path; three batches are in flight per consumer.
+        const std::string d = argv[1];
+        Sink s;
+        Parameter pf = p;
+        pf.numThreads = 4;
+        pf.batch = 8;
+        Manager* mg = new Manager(observer(s));
+        mg->start(pf);
+        const int N = 400;
+        int want_err = 0;
+        long want_hits_min = 0;
+        for (int j = 0; j < N; j++) {
+            const int kind = (j / 16) % 2 == 0 ? j % 2 : j % 5;  // runs of 16 all-eligible pairs, then mixed ones
+            const char* t = kind == 0 ? "e.png" : kind == 1 ? "t.png" : kind == 2 ? "t5.png" : kind == 3 ? "pal.png" : "bad.png";
+            if (kind == 4) want_err++;
+            if (kind == 1) want_hits_min++;
+            mg->request(d + "/e.png", d + "/" + t);
+        }
+        {
+            std::unique_lock<std::mutex> lk(s.m);
+            s.cv.wait(lk, [&] { return s.data + s.err >= N; });
+        }
+        mg->stop();
+        {
+            std::unique_lock<std::mutex> lk(s.m);
+            s.cv.wait(lk, [&] { return s.completed; });
+        }
+        delete mg;
+        if (s.err != want_err || s.data != N - want_err || s.hits < want_hits_min) {
+            fprintf(stderr, "files: data %ld err %ld hits %ld (want %d %d >= %ld)\n", s.data, s.err, s.hits, N - want_err,
+                    want_err, want_hits_min);
+            rc = 1;
+        }
     }
     printf("tsan driver: %s\n", rc ? "FAILED" : "ok");
     return rc;

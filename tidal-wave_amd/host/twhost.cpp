@@ -333,20 +333,20 @@ struct PngStream {
     std::unique_ptr<uint8_t[]> raw;  // `total` bytes of filtered rows (+ 8 bytes of slack)
     size_t total = 0;
     int w = 0, h = 0, depth = 0, ctype = 0, interlace = 0, ch = 0;
-    std::vector<uint8_t> plte;
+    std::vector<uint8_t> plte, idat;  // idat: the concatenated IDAT chunks between png_parse and png_inflate
     // 8-bit, not interlaced, gray / gray + alpha / RGB / RGBA: rows the device reconstructs (tw_submit_png8)
     bool device_rows() const { return depth == 8 && !interlace && ctype != 3; }
 };
 
-// stage 1 of cv::imread on a PNG: chunk walk (libpng's rules) + inflate
-static bool png_parse_inflate(const std::vector<uint8_t>& d, PngStream& ps)
+// stage 1a of cv::imread on a PNG: the chunk walk (libpng's rules); the IDAT stream is gathered in ps.idat
+static bool png_parse(const std::vector<uint8_t>& d, PngStream& ps)
 {
     int w = 0, h = 0;
     static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
     if (d.size() < 33 || memcmp(d.data(), sig, 8) != 0) return false;
     size_t p = 8;
     int depth = 0, ctype = 0, interlace = 0;
-    std::vector<uint8_t> idat;
+    std::vector<uint8_t>& idat = ps.idat;
     std::vector<uint8_t>& plte = ps.plte;
     bool have_ihdr = false, idat_done = false, first = true;
     // Chunk rules the way libpng (cv::imread) enforces them — a file it refuses answers "Can't open" here as well
@@ -407,14 +407,9 @@ static bool png_parse_inflate(const std::vector<uint8_t>& d, PngStream& ps)
         const int ph = interlace ? (h - AY0[ps] + ADY[ps] - 1) / ADY[ps] : h;
         if (pw > 0 && ph > 0) total += (((size_t)pw * bpp_bits + 7) / 8 + 1) * (size_t)ph;
     }
-    // (uninitialised: every byte is written by the inflate or the decode fails; + 8 bytes of slack for nothing — the
-    // decoder never writes past `total`)
     // DEFLATE expands by at most 1032 : 1: a stream too short for the image the header announces is refused before
     // `total` bytes (up to 8 GiB for 32768 x 32768 RGBA16) are allocated for it
     if (total / 1032 > idat.size()) return false;
-    ps.raw.reset(new (std::nothrow) uint8_t[total + 8]);
-    if (!ps.raw) return false;
-    uint8_t* const raw = ps.raw.get();
     ps.total = total;
     ps.w = w;
     ps.h = h;
@@ -422,9 +417,26 @@ static bool png_parse_inflate(const std::vector<uint8_t>& d, PngStream& ps)
     ps.ctype = ctype;
     ps.interlace = interlace;
     ps.ch = ch;
-    size_t outlen = 0;
-    if (!tw_inflate_zlib(idat.data(), idat.size(), raw, total, &outlen) || outlen != total) return false;
     return true;
+}
+
+// stage 1b: the inflate, into `dst` (ps.total bytes + 8 of slack: the caller's arena slot, or ps.raw)
+static bool png_inflate(const PngStream& ps, uint8_t* dst)
+{
+    size_t outlen = 0;
+    return tw_inflate_zlib(ps.idat.data(), ps.idat.size(), dst, ps.total, &outlen) && outlen == ps.total;
+}
+
+static bool png_parse_inflate(const std::vector<uint8_t>& d, PngStream& ps)
+{
+    if (!png_parse(d, ps)) return false;
+    // (uninitialised: every byte is written by the inflate or the decode fails; + 8 bytes of slack for nothing — the
+    // decoder never writes past `total`)
+    ps.raw.reset(new (std::nothrow) uint8_t[ps.total + 8]);
+    if (!ps.raw) return false;
+    const bool ok = png_inflate(ps, ps.raw.get());
+    std::vector<uint8_t>().swap(ps.idat);
+    return ok;
 }
 
 // stage 2: scanline reconstruction (tw_inflate.cpp) + conversion to 8-bit gray with libpng 1.5's formula — on the host
@@ -518,6 +530,8 @@ bool finish_png_rows_on_host(std::vector<uint8_t>& rows, int w, int h, int ch, s
     return png_finish_on_host(st, gray);
 }
 
+static bool decode_gray_or_png_rows(const std::vector<uint8_t>& d, bool want_rows, std::vector<uint8_t>& img, int& w, int& h, int& ch);
+
 bool load_gray(const std::string& path, std::vector<uint8_t>& img, int& w, int& h)
 {
     int ch = 0;
@@ -532,7 +546,15 @@ bool load_gray_or_png_rows(const std::string& path, bool want_rows, std::vector<
 {
     std::vector<uint8_t> d;
     w = h = ch = 0;
-    if (!read_file(path, d) || d.size() < 8) return false;
+    if (!read_file(path, d)) return false;
+    return decode_gray_or_png_rows(d, want_rows, img, w, h, ch);
+}
+
+// the same on the bytes of a file that has been read already
+static bool decode_gray_or_png_rows(const std::vector<uint8_t>& d, bool want_rows, std::vector<uint8_t>& img, int& w, int& h, int& ch)
+{
+    w = h = ch = 0;
+    if (d.size() < 8) return false;
     bool ok = false;
     if (d[0] == 'P' && d[1] >= '1' && d[1] <= '6') ok = decode_pnm(d, img, w, h);
     else if (d[0] == 0x89 && d[1] == 'P' && want_rows) {
@@ -648,16 +670,19 @@ struct Staged {
 };
 
 // the two imreads of a pair are independent: the decode pool runs them as separate tasks (task = 2 * job + image)
-void decode_one(Staged& s, int which, int* tw, int* th, std::string* err, bool device_png)
+// (`file`: the bytes of the file when the caller has read it already, else null)
+void decode_one(Staged& s, int which, int* tw, int* th, std::string* err, bool device_png, const std::vector<uint8_t>* file)
 {
     if (s.req.raw.expect) return;
-    if (which == 0) {
-        if (s.req.expect_image.empty()) { *err = "ExpectImagePath is empty."; return; }
-        if (!load_gray_or_png_rows(s.req.expect_image, device_png, s.a, s.w, s.h, s.cha)) *err = "Can't open " + s.req.expect_image;
-    } else {
-        if (s.req.target_image.empty()) { *err = "TargetImagePath is empty."; return; }
-        if (!load_gray_or_png_rows(s.req.target_image, device_png, s.b, *tw, *th, s.chb)) *err = "Can't open " + s.req.target_image;
-    }
+    const std::string& path = which == 0 ? s.req.expect_image : s.req.target_image;
+    if (path.empty()) { *err = which == 0 ? "ExpectImagePath is empty." : "TargetImagePath is empty."; return; }
+    std::vector<uint8_t>& img = which == 0 ? s.a : s.b;
+    int& w = which == 0 ? s.w : *tw;
+    int& h = which == 0 ? s.h : *th;
+    int& ch = which == 0 ? s.cha : s.chb;
+    const bool ok = file ? decode_gray_or_png_rows(*file, device_png, img, w, h, ch)
+                         : load_gray_or_png_rows(path, device_png, img, w, h, ch);
+    if (!ok) *err = "Can't open " + path;
 }
 
 // OpticalFlow::calculate up to (not including) calculateInternal: src/opticalflow.cpp:20-68
@@ -760,16 +785,24 @@ void Consumer::run()
     mine.engineError = eng_err;
     publish();
     // wait for one job and hand its response to the pump
+    // (one scratch array for the hit records of a job, grown to the largest grid seen: a fresh zero-filled vector of
+    // grid-capacity entries per job — 0.5 MB at 1080p / span 10 — cost 0.2 ms of every response, round 4)
+    std::unique_ptr<tw_vector[]> hits;
+    size_t hits_cap = 0;
     auto finish = [&](Staged& s) {
         if (s.done) return;
         s.done = true;
         Response res;
         if (s.submitted) {
             const int cap = std::max(1, tw_grid_capacity(s.w, s.h, s.req.span));
-            std::vector<tw_vector> v((size_t)cap);
+            if ((size_t)cap > hits_cap) {
+                hits.reset(new tw_vector[(size_t)cap]);
+                hits_cap = (size_t)cap;
+            }
+            tw_vector* const v = hits.get();
             int n = 0;
             float sec = 0;
-            tw_status r = tw_wait(eng, s.ticket, v.data(), cap, &n, &sec);
+            tw_status r = tw_wait(eng, s.ticket, v, cap, &n, &sec);
             if (r != TW_OK) {
                 s.err = std::string(tw_last_error(eng)[0] ? tw_last_error(eng) : tw_strerror(r));
             } else {
@@ -802,9 +835,13 @@ void Consumer::run()
     struct Arena {
         uint8_t* base = nullptr;
         size_t cap = 0;
-    } arena[2];  // page-locked (tw_host_alloc): the decoded pairs of the batch being filled / the batch in flight
+    } arena[3];  // page-locked (tw_host_alloc): the decoded pairs of the batch being filled / the two batches in flight
     int arena_idx = 0;
-    std::vector<Staged> prev;
+    // Batches in flight behind the one being prepared: `prev` was submitted last, `prev2` before it.  Round 4: with one
+    // batch in flight the loop ran at the GPU's LATENCY for a batch (upload -> scanline reconstruction -> flow: ~22 ms for
+    // 32 pairs) instead of at the host's own ~16 ms; the engine takes three batch contexts, so two stay outstanding while
+    // the third is decoded.
+    std::vector<Staged> prev, prev2;
     auto finish_all = [&](std::vector<Staged>& v) {
         for (Staged& s : v) finish(s);
         v.clear();
@@ -812,7 +849,8 @@ void Consumer::run()
     for (;;) {
         Request first;
         if (!req_.tryPopNow(first)) {
-            finish_all(prev);  // nothing queued: deliver what is outstanding before blocking
+            finish_all(prev2);  // nothing queued: deliver what is outstanding before blocking
+            finish_all(prev);
             read_prof(true);   // idle: nothing of ours is in flight, so the event read's synchronise costs nothing
             publish();
             const long long w0 = steady_ns();
@@ -846,6 +884,9 @@ void Consumer::run()
             for (const Staged& s : jobs)  // src/consumer.cpp:49
                 TW_LOGF("consume: %s <-> %s\n", s.req.expect_image.c_str(), s.req.target_image.c_str());
         mine.batches++;
+        static const bool batch_time = getenv("TW_DEBUG_BATCHTIME") != nullptr;  // diagnostic: where a batch's host time goes
+        const long long bt0 = steady_ns();
+        long long bt1 = bt0, bt2 = bt0, bt3 = bt0;
         // decode pool: once the flow runs on the GPU the two imreads of a pair are > 99 % of the wall time
         // (SURVEY §8 f1), so the pairs of a batch are decoded side by side
         {
@@ -862,33 +903,32 @@ void Consumer::run()
                 worker();
                 for (std::thread& t : pool) t.join();
             };
+            // Phase 1 (pool): read every file.  A PNG the device can finish (8-bit, not interlaced, no palette) is only
+            // PARSED here; when every image of the batch is one, the arena is sized from the headers and the pool
+            // inflates straight into it (round 4: the intermediate buffers — inflate output, its copy, the copy into the
+            // arena, three 2 MB allocations per 1080p image — were a third of a batch's host time).
+            struct Opened {
+                std::vector<uint8_t> file;
+                PngStream st;
+                bool read_ok = false, rows_ok = false;
+            };
+            std::vector<Opened> op(2 * jobs.size());
             parallel_for(2 * jobs.size(), [&](size_t i) {
-                const size_t j = i >> 1;
-                decode_one(jobs[j], (int)(i & 1), &tw[j], &th[j], (i & 1) ? &eb[j] : &ea[j], device_png);
+                const Staged& s = jobs[i >> 1];
+                const std::string& path = (i & 1) ? s.req.target_image : s.req.expect_image;
+                if (s.req.raw.expect || path.empty()) return;
+                Opened& o = op[i];
+                o.read_ok = read_file(path, o.file);
+                if (o.read_ok && device_png && eng && o.file.size() >= 8 && o.file[0] == 0x89 && o.file[1] == 'P')
+                    o.rows_ok = png_parse(o.file, o.st) && o.st.device_rows();
             });
-            // Second pass, still in the pool: size reconcile, then the pair moves into this batch's page-locked arena,
-            // so that tw_submit_u8 DMAs straight from it.  Round 3: with the decode itself 2.6x faster, the staging
-            // copy tw_submit_u8 makes of pageable images (2 x 2 MB per 1080p pair, on this one thread, batch after
-            // batch) had become a quarter of a batch's time.  Two arenas alternate: the previous batch's is still
-            // being uploaded from while this one fills.
-            parallel_for(jobs.size(), [&](size_t j) { prepare(jobs[j], tw[j], th[j], ea[j], eb[j]); });
-            // The arena is sized AFTER prepare(), over the pairs that decoded and reconciled (ADVICE r3: a header with
-            // huge dimensions over a damaged stream must not size it), and it is bounded: a pair larger than
-            // kArenaSlotMax, or one the bounded arena has no room for, keeps its pageable buffers (tw_submit_u8 stages
-            // those itself — always correct, one memcpy slower).
             constexpr size_t kArenaSlotMax = (size_t)64 << 20;  // one 8192 x 8192 image
-            constexpr size_t kArenaMax = (size_t)4 << 30;       // per arena, two arenas per consumer
-            size_t slot = 0;
-            for (const Staged& s : jobs) {
-                if (!s.err.empty() || s.req.raw.expect) continue;
-                // (an image is w * h gray bytes or, still filtered, h * (1 + w * ch) bytes)
-                const size_t nb = (std::max(s.a.size(), s.b.size()) + 255) / 256 * 256;
-                if (nb <= kArenaSlotMax) slot = std::max(slot, nb);
-            }
-            Arena& ar = arena[arena_idx];
-            arena_idx ^= 1;
-            const size_t need = std::min(kArenaMax, slot * 2 * jobs.size());
-            if (eng && slot && need > ar.cap) {
+            constexpr size_t kArenaMax = (size_t)4 << 30;       // per arena, three arenas per consumer
+            Arena& ar = arena[arena_idx];  // (its last user was the batch three back: collected below before this one)
+            arena_idx = (arena_idx + 1) % 3;
+            auto ensure_arena = [&](size_t slot) {
+                const size_t need = std::min(kArenaMax, slot * 2 * jobs.size());
+                if (!eng || !slot || need <= ar.cap) return;
                 if (ar.base) (void)tw_host_free(eng, ar.base);
                 ar.base = nullptr;
                 ar.cap = 0;
@@ -899,7 +939,78 @@ void Consumer::run()
                     ar.base = (uint8_t*)hp;
                     ar.cap = want;
                 }
+            };
+            bool fast = !op.empty();
+            size_t fslot = 0;
+            for (const Opened& o : op) {
+                fast = fast && o.rows_ok;
+                fslot = std::max(fslot, (o.st.total + 8 + 255) / 256 * 256);
             }
+            fast = fast && fslot <= kArenaSlotMax;
+            if (fast) {
+                ensure_arena(fslot);
+                fast = ar.base && fslot * 2 * jobs.size() <= ar.cap;
+            }
+            if (fast) {
+                // Phase 2 (pool): inflate into the arena slot; every row's filter type is checked as libpng does
+                parallel_for(2 * jobs.size(), [&](size_t i) {
+                    Opened& o = op[i];
+                    uint8_t* dst = ar.base + fslot * i;
+                    bool ok = png_inflate(o.st, dst);
+                    const size_t rs = (size_t)o.st.w * o.st.ch + 1;
+                    for (int y = 0; y < o.st.h && ok; y++) ok = dst[(size_t)y * rs] <= 4;
+                    if (!ok) {
+                        const Staged& s = jobs[i >> 1];
+                        ((i & 1) ? eb : ea)[i >> 1] = "Can't open " + ((i & 1) ? s.req.target_image : s.req.expect_image);
+                    }
+                    std::vector<uint8_t>().swap(o.file);
+                    std::vector<uint8_t>().swap(o.st.idat);
+                });
+                bt1 = steady_ns();
+                for (size_t j = 0; j < jobs.size(); j++) {
+                    Staged& s = jobs[j];
+                    const PngStream &sa = op[2 * j].st, &sb = op[2 * j + 1].st;
+                    // the reference opens the expected image first: its error wins (src/opticalflow.cpp:26-48)
+                    if (!ea[j].empty()) { s.err = ea[j]; continue; }
+                    if (!eb[j].empty()) { s.err = eb[j]; continue; }
+                    s.w = sa.w;
+                    s.h = sa.h;
+                    s.cha = sa.ch;
+                    s.chb = sb.ch;
+                    uint8_t* da = ar.base + fslot * (2 * j);
+                    uint8_t* db = da + fslot;
+                    if (sa.w == sb.w && sa.h == sb.h) {
+                        s.pa = da;
+                        s.pb = db;
+                        s.stride = s.w;
+                        continue;
+                    }
+                    // sizes differ: the <= 5 px reconcile (or the refusal) of prepare(), on copies outside the arena
+                    s.a.assign(da, da + sa.total);
+                    s.b.assign(db, db + sb.total);
+                    prepare(s, sb.w, sb.h, std::string(), std::string());
+                }
+            } else {
+            parallel_for(2 * jobs.size(), [&](size_t i) {
+                const size_t j = i >> 1;
+                decode_one(jobs[j], (int)(i & 1), &tw[j], &th[j], (i & 1) ? &eb[j] : &ea[j], device_png,
+                           op[i].read_ok ? &op[i].file : nullptr);
+                std::vector<uint8_t>().swap(op[i].file);
+            });
+            bt1 = steady_ns();
+            parallel_for(jobs.size(), [&](size_t j) { prepare(jobs[j], tw[j], th[j], ea[j], eb[j]); });
+            // The arena is sized AFTER prepare(), over the pairs that decoded and reconciled (ADVICE r3: a header with
+            // huge dimensions over a damaged stream must not size it), and it is bounded: a pair larger than
+            // kArenaSlotMax, or one the bounded arena has no room for, keeps its pageable buffers (tw_submit_u8 stages
+            // those itself — always correct, one memcpy slower).
+            size_t slot = 0;
+            for (const Staged& s : jobs) {
+                if (!s.err.empty() || s.req.raw.expect) continue;
+                // (an image is w * h gray bytes or, still filtered, h * (1 + w * ch) bytes)
+                const size_t nb = (std::max(s.a.size(), s.b.size()) + 255) / 256 * 256;
+                if (nb <= kArenaSlotMax) slot = std::max(slot, nb);
+            }
+            ensure_arena(slot);
             parallel_for(jobs.size(), [&](size_t j) {
                 Staged& s = jobs[j];
                 if (!s.err.empty() || s.req.raw.expect || !ar.base || !slot) return;
@@ -913,7 +1024,9 @@ void Consumer::run()
                 std::vector<uint8_t>().swap(s.a);
                 std::vector<uint8_t>().swap(s.b);
             });
+            }  // !fast
         }
+        bt2 = steady_ns();
         // one engine batch is homogeneous in size: group equal sizes so that a mixed queue makes few batches
         // (responses are delivered in completion order anyway, like the reference's)
         std::stable_sort(jobs.begin(), jobs.end(), [](const Staged& x, const Staged& y) {
@@ -932,6 +1045,7 @@ void Consumer::run()
             if (r == TW_E_BUSY) {
                 // every batch context of the engine is owed to us (each size change opens one): collect what
                 // is outstanding, then this job starts a fresh batch
+                finish_all(prev2);
                 finish_all(prev);
                 for (size_t q = 0; q < k; q++) finish(jobs[q]);
                 r = submit();
@@ -940,11 +1054,19 @@ void Consumer::run()
             else s.err = std::string(tw_last_error(eng)[0] ? tw_last_error(eng) : tw_strerror(r));
         }
         if (eng) (void)tw_flush(eng);  // a partly filled batch starts now, not when its first result is asked for
+        bt3 = steady_ns();
+        const size_t njobs = jobs.size();
         for (Staged& s : jobs)
             if (!s.submitted) finish(s);  // errors do not wait for the GPU
-        finish_all(prev);
+        finish_all(prev2);  // the batch before the previous one: its results have had two batches' time to arrive
+        prev2 = std::move(prev);
         prev = std::move(jobs);
+        if (batch_time)
+            fprintf(stderr, "twhost: consumer %d batch of %zu: decode %.2f ms, prepare + arena %.2f, submit + flush %.2f, "
+                            "previous batch's results %.2f\n", id_, njobs, (bt1 - bt0) * 1e-6, (bt2 - bt1) * 1e-6,
+                    (bt3 - bt2) * 1e-6, (steady_ns() - bt3) * 1e-6);
     }
+    finish_all(prev2);
     finish_all(prev);
     read_prof(true);
     publish();

@@ -10,7 +10,7 @@
 //
 //   bench_queue --pgm-dir DIR [--pairs 2048] [--devices 0] [--per-device 1] [--batch 128] [--warmup-batches 2]
 //               [--pinned 1] [--files 0] [--span 10] [--threshold 5] [--prof 1]
-// DIR holds pair_<i>_a.pgm / pair_<i>_b.pgm (i = 0..), written by bench.py / tests from tidal-wave_amd/synth.py.
+// DIR holds pair_<i>_a.pgm / pair_<i>_b.pgm (i = 0..; or .png), written by bench.py / tests from tidal-wave_amd/synth.py.
 // Prints one JSON line.
 #include <stdio.h>
 #include <stdlib.h>
@@ -107,8 +107,12 @@ int main(int argc, char** argv)
             snprintf(path, sizeof(path), "%s/pair_%d_%c.pgm", a.dir.c_str(), i, q ? 'b' : 'a');
             Img im;
             if (!load_gray(path, im.pageable, im.w, im.h)) {
-                ok = false;
-                break;
+                // (--files 1 also takes PNG pairs: the decode pool then runs its half-decode + device path)
+                snprintf(path, sizeof(path), "%s/pair_%d_%c.png", a.dir.c_str(), i, q ? 'b' : 'a');
+                if (!load_gray(path, im.pageable, im.w, im.h)) {
+                    ok = false;
+                    break;
+                }
             }
             im.data = im.pageable.data();
             if (alloc_eng) {

@@ -42,7 +42,7 @@ def main():
     r = subprocess.run(["node", "-e", js, os.path.join(d, "target"), os.path.join(d, "expected")],
                        cwd=os.path.join(ROOT, "tidal-wave_amd", "host"), capture_output=True, text=True, env=env)
     wall = time.time() - t0
-    print(r.stdout.strip(), r.stderr.strip()[-300:])
+    print(r.stdout.strip(), r.stderr.strip()[-3000:])
     out = json.loads(r.stdout.strip().splitlines()[-1])
     print("pairs %d  decode_threads %s  service %.1f pairs/s (node wall %.2fs)" %
           (n, threads or "auto", n / (out["ms"] / 1e3), wall))
