@@ -12,7 +12,7 @@ mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 timeout -k 10 600 python3 bench.py > "$out/bench.log" 2>&1; grep '^{' "$out/bench.log" | tail -1 > "$out/bench.json"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -o run -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > "$out/trace.log" 2>&1
-python3 tools/rocprof_summary.py "$out/trace" "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras (single stream, 256-pair steps = 2 engine batches of 128, one launch per kernel and level for a whole batch)" > "$out/kernel_trace_summary.md"
+python3 tools/rocprof_summary.py "$out/trace" "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras (default mode: 256-pair steps from page-locked host memory, uploads on the copy stream; single compute stream, 2 engine batches of 128 per step, one launch per kernel and level for a whole batch)" > "$out/kernel_trace_summary.md"
 cp "$out"/trace/*kernel_stats.csv "$out/kernel_stats.csv" 2>/dev/null
 grep '^{' "$out/trace.log" | tail -1 > "$out/bench_under_rocprof.json"
 for c in FETCH_SIZE WRITE_SIZE; do
