@@ -619,7 +619,8 @@ def test_two_stream_lanes_gaussian_and_box(twflow, oracle, kw, monkeypatch):
                                  dict(TW_PP_WAVES="100000"), dict(TW_CHUNK_TILES="100"), dict(TW_LANES="2", TW_CHUNK_TILES="100"),
                                  dict(TW_BLUR_VARIANT="2"), dict(TW_BLUR_VARIANT="6"), dict(TW_BLUR_VARIANT="7"),
                                  dict(TW_BLUR_VARIANT="8"), dict(TW_UPD_NY="1"), dict(TW_LAT_GRAPH="1"), dict(TW_LAT_S2_LEVELS="0"),
-                                 dict(TW_BLUR_PIPE="9"), dict(TW_BLUR_PIPE="109"), dict(TW_BLUR_PIPE="3")])
+                                 dict(TW_BLUR_PIPE="9"), dict(TW_BLUR_PIPE="109"), dict(TW_BLUR_PIPE="3"),
+                                 dict(TW_BLUR_VARIANT="9"), dict(TW_BLUR_VARIANT="9", TW_BLUR_NOMASK="1")])
 def test_every_kernel_variant_behind_a_switch_is_bit_exact(twflow, oracle, env, monkeypatch):
     """The A/B switches of DESIGN.md §7 select other kernels / schedules for the same arithmetic (small-grid blur
     tiles, the plane-parallel blur, scalar / 240x16 polyexp, one- or two-stream single-pair schedule, 480-column

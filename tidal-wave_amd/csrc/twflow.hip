@@ -1023,6 +1023,11 @@ void launch_blur(tw_engine* e, hipStream_t st, int w, int h, int ld, long long p
         a.xsh = ((w + 16 + tw - 1) / tw == (w + tw - 1) / tw) ? 16 : 0;
         a.rot = a.xsh;
 #ifdef TW_VARIANTS
+        if (e->blur_variant == 9) {  // round 4: solve + refresh by the horizontal item's owner, 16-byte R0 / M accesses
+            if (wide) hipLaunchKernelGGL((tw_blur_solve4q<15, 256, 16, 8, true>), dim3((w + a.xsh + 223) / 224, gy, npairs), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((tw_blur_solve4q<15, 128, 16, 8, true>), dim3((w + a.xsh + 95) / 96, gy, npairs), dim3(128), 0, st, a);
+            return;
+        }
         if (wide && e->blur_variant == 2) { hipLaunchKernelGGL((tw_blur_solve4y<15, 256, 16, 8, 2>), dim3((w + a.xsh + 223) / 224, (h + 15) / 16, npairs), dim3(256), 0, st, a); return; }
         if (wide && e->blur_variant == 7) { hipLaunchKernelGGL((tw_blur_solve4<15, 256, 16, 8, true, 2, 2, 2, true, false>), dim3((w + a.xsh + 223) / 224, gy, npairs), dim3(256), 0, st, a); return; }
         if (wide && e->blur_variant == 6) { hipLaunchKernelGGL((tw_blur_solve4<15, 256, 16, 8, true, 2, 2, 2, false>), dim3((w + a.xsh + 223) / 224, gy, npairs), dim3(256), 0, st, a); return; }

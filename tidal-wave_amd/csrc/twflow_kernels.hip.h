@@ -1655,6 +1655,184 @@ __global__ __launch_bounds__(COLS) __attribute__((amdgpu_waves_per_eu(4, 8))) vo
     }
 }
 
+#ifdef TW_VARIANTS
+// -----------------------------------------------------------------------------------------------------
+// tw_blur_solve4q<MH,COLS,HALO,TH,FUSED> (round 4): tw_blur_solve4 with the solve + refresh done BY THE HORIZONTAL ITEM'S
+//   OWNER, four pixels of one row per lane.  The horizontal pass already leaves the window averages of a 4-pixel group in
+//   its lane's registers (all five planes); tw_blur_solve4 writes them back to the LDS tile, barriers twice and reads them
+//   lane-consecutively (one pixel per lane) so that the refresh's accesses are dwords.  Here they never leave the
+//   registers: R0 comes in and M goes out as 16-byte accesses per lane (the refresh replay of round 4: 16-byte R0 / M
+//   accesses + per-pixel dword taps move the same bytes 4-6 % faster, profiles/r04_refresh_shape.txt), two of the three
+//   workgroup barriers and 55 LDS accesses per lane and tile go away.  Same values, same order per value.
+//   MEASURED (profiles/r04_blur_quads.md): the last launch of a level -4 %, the refreshing launch +12 % (the 2x2 taps of
+//   lanes that sit 16 bytes apart touch four times the cache lines per instruction) — variants library only
+//   (TW_BLUR_VARIANT=9).
+// -----------------------------------------------------------------------------------------------------
+template <int MH, int COLS, int HALO, int TH, bool FUSED, int VILP = 2, int HILP = 2>
+__global__ __launch_bounds__(COLS) __attribute__((amdgpu_waves_per_eu(4, 8))) void tw_blur_solve4q(BlurArgs a)
+{
+    constexpr int TW = COLS - 2 * HALO;
+    constexpr int NW = TH + 2 * MH;
+    __shared__ __attribute__((aligned(16))) float sm[5][TH][COLS];
+    const int tid = threadIdx.x;
+    int bx, by, z;
+    xcd_remap(bx, by, z);
+    const int x0 = bx * TW - a.xsh, y0 = by * TH;  // xsh is 0 or 16: x0 is a multiple of 4
+    const WinCoef& c = a.c;
+    const float* __restrict__ Min = a.Min + (long long)z * 5 * a.ps;
+    float* __restrict__ flow = a.flow + (long long)z * 2 * a.fps;
+    const int cx0 = max(0, -x0), vw = min(TW, a.w - x0) - cx0;
+    const bool partial = !a.nomask && vw <= TW - 32;
+    const int gq0 = cx0 >> 2, gv = ((cx0 + vw + 3) >> 2) - gq0;  // 4-pixel groups with a valid pixel
+    const float inv_gv = 1.f / (float)gv;
+
+    // ---- V (as tw_blur_solve4) ----
+    if (a.nomask || (x0 - HALO + tid >= -MH && x0 - HALO + tid <= a.w - 1 + MH)) {
+        const unsigned xb = (unsigned)clampi(x0 - HALO + tid, 0, a.w - 1) * 4u;
+        unsigned ro[NW];
+#pragma unroll
+        for (int i = 0; i < NW; i++) ro[i] = (unsigned)clampi(y0 - MH + i, 0, a.h - 1) * ((unsigned)a.ld * 4u);
+        float wa[NW], wb[NW];
+        {
+            const __amdgpu_buffer_rsrc_t rs = make_rsrc(Min);
+#pragma unroll
+            for (int i = 0; i < NW; i++) wa[i] = bload(rs, xb, ro[i]);
+        }
+#pragma unroll
+        for (int ch = 0; ch < 5; ch++) {
+            float* cur = (ch & 1) ? wb : wa;
+            float* nxt = (ch & 1) ? wa : wb;
+            if (ch < 4) {
+                const __amdgpu_buffer_rsrc_t rs = make_rsrc(Min + (long long)(ch + 1) * a.ps);
+#pragma unroll
+                for (int i = 0; i < NW; i++) nxt[i] = bload(rs, xb, ro[i]);
+            }
+#pragma unroll
+            for (int r = 0; r < TH; r++) {
+                float s0 = cur[r + MH] * c.k[0];
+#pragma unroll
+                for (int i = 1; i <= MH; i++) s0 += (cur[r + MH + i] + cur[r + MH - i]) * c.k[i];
+                sm[ch][r][tid] = s0;
+                if ((r & (VILP - 1)) == VILP - 1) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- H + S: one 4-pixel item at a time, its owner solves and refreshes it ----
+    constexpr int GROUPS = TW / 4;
+    constexpr int NITEM = TH * GROUPS;
+    constexpr int ROUNDS = (NITEM + COLS - 1) / COLS;
+    constexpr int WL = 4 + 2 * HALO;
+    float* __restrict__ Mout = a.Mout + (long long)z * 5 * a.ps;
+    const float* __restrict__ R0 = a.R + (long long)(2 * z) * 5 * a.ps;
+    const float* __restrict__ R1 = R0 + 5 * a.ps;
+#pragma unroll
+    for (int rd = 0; rd < ROUNDS; rd++) {
+        const int it = tid + rd * COLS;
+        int r, q;
+        bool on;
+        if (partial) {
+            on = it < TH * gv;
+            r = (int)(((float)it + 0.5f) * inv_gv);
+            q = gq0 + it - r * gv;
+        } else {
+            r = it / GROUPS;
+            q = it - r * GROUPS;
+            on = it < NITEM && (a.nomask || (x0 + 4 * q < a.w && x0 + 4 * q + 3 >= 0));
+        }
+        if (!on) continue;
+        const int x = x0 + 4 * q, y = y0 + r;
+        const int yc = min(y, a.h - 1);
+        const bool full = y < a.h && x >= 0 && x + 3 < a.w;  // the whole group lies inside the image
+        const long long o = (long long)yc * a.ld + x;        // (used when full)
+        // the R0 coefficients do not depend on the flow: fetched now, they fly under the horizontal arithmetic
+        f32x4 q4[5];
+        if (FUSED && a.update) {
+            if (full) {
+#pragma unroll
+                for (int cc = 0; cc < 5; cc++) q4[cc] = *(const f32x4*)(R0 + o + cc * a.ps);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const long long oj = (long long)yc * a.ld + clampi(x + j, 0, a.w - 1);
+#pragma unroll
+                    for (int cc = 0; cc < 5; cc++) q4[cc][j] = R0[oj + cc * a.ps];
+                }
+            }
+        }
+        f32x4 res[5];
+#pragma unroll
+        for (int ch = 0; ch < 5; ch++) {
+            float v[WL];
+#pragma unroll
+            for (int u = 0; u < WL / 4; u++) {
+                const f32x4 A = *(const f32x4*)&sm[ch][r][4 * q + 4 * u];
+                v[4 * u] = A[0];
+                v[4 * u + 1] = A[1];
+                v[4 * u + 2] = A[2];
+                v[4 * u + 3] = A[3];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int li = HALO + j;
+                float sum = v[li] * c.k[0];
+#pragma unroll
+                for (int i = 1; i <= MH; i++) sum += c.k[i] * (v[li - i] + v[li + i]);
+                res[ch][j] = sum;
+                if ((j & (HILP - 1)) == HILP - 1) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        f32x4 fx4, fy4;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const double g11 = res[0][j], g12 = res[1][j], g22 = res[2][j], h1 = res[3][j], h2 = res[4][j];
+            const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
+            fx4[j] = (float)((g11 * h2 - g12 * h1) * idet);
+            fy4[j] = (float)((g22 * h1 - g12 * h2) * idet);
+        }
+        if (!a.update || a.store_flow) {
+            if (full) {
+                *(f32x4*)(flow + o) = fx4;
+                *(f32x4*)(flow + o + a.fps) = fy4;
+            } else if (y < a.h) {
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    if (x + j >= 0 && x + j < a.w) {
+                        flow[(long long)yc * a.ld + x + j] = fx4[j];
+                        flow[(long long)yc * a.ld + x + j + a.fps] = fy4[j];
+                    }
+            }
+        }
+        if (FUSED) {
+            if (a.update) {  // wave-uniform
+                f32x4 M4[5];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if ((j & 1) == 0) __builtin_amdgcn_sched_barrier(0);  // two pixels' gathers in flight
+                    const float qj[5] = {q4[0][j], q4[1][j], q4[2][j], q4[3][j], q4[4][j]};
+                    float M[5];
+                    update_matrices_core(qj, R1, a.ps, a.ld, a.w, a.h, clampi(x + j, 0, a.w - 1), yc, fx4[j], fy4[j], M);
+#pragma unroll
+                    for (int cc = 0; cc < 5; cc++) M4[cc][j] = M[cc];
+                }
+                if (full) {
+#pragma unroll
+                    for (int cc = 0; cc < 5; cc++) st_stream<0>((f32x4*)(Mout + o + cc * a.ps), M4[cc]);
+                } else if (y < a.h) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        if (x + j >= 0 && x + j < a.w) {
+#pragma unroll
+                            for (int cc = 0; cc < 5; cc++) Mout[(long long)yc * a.ld + x + j + cc * a.ps] = M4[cc][j];
+                        }
+                }
+            }
+        }
+    }
+}
+#endif  // TW_VARIANTS (tw_blur_solve4q)
+
 #ifdef TW_VARIANTS  // round-3 trial (TW_BLUR_PIPE), measured 55 % slower: VARIANTS=1 builds only (profiles/r03_blur_pipeline_negative.md)
 // -----------------------------------------------------------------------------------------------------
 // tw_blur_solve4p<MH,COLS,HALO,TH,NT> : tw_blur_solve4's refreshing launch as a CROSS-TILE PIPELINE.
