@@ -2229,18 +2229,38 @@ double tw_min_traffic_bytes_pair(const tw_engine* e, int width, int height, int 
 
 // ---- per-stage entry points (tests) --------------------------------------------------------------------
 namespace {
+// (through the engine's page-locked bounce buffer, like tw_flow_u8: the runtime is never handed a pageable pointer for a
+// pitched copy — round 4)
+tw_status bounce_reserve(tw_engine* e, size_t bytes)
+{
+    if (bytes <= e->h_bounce_cap) return TW_OK;
+    if (e->h_bounce) (void)hipHostFree(e->h_bounce);
+    e->h_bounce = nullptr;
+    e->h_bounce_cap = 0;
+    TW_HIP(e, hipHostMalloc((void**)&e->h_bounce, bytes, hipHostMallocDefault));
+    e->h_bounce_cap = bytes;
+    return TW_OK;
+}
 tw_status up_planes(tw_engine* e, float* d, int ld, long long ps, const float* h, int w, int hh, int planes)
 {
-    for (int c = 0; c < planes; c++)
-        TW_HIP(e, hipMemcpy2D(d + c * ps, (size_t)ld * 4, h + (size_t)c * w * hh, (size_t)w * 4, (size_t)w * 4, hh,
-                              hipMemcpyHostToDevice));
+    const size_t plane = (size_t)w * hh * 4;
+    tw_status r = bounce_reserve(e, plane);
+    if (r) return r;
+    for (int c = 0; c < planes; c++) {
+        memcpy(e->h_bounce, h + (size_t)c * w * hh, plane);
+        TW_HIP(e, hipMemcpy2D(d + c * ps, (size_t)ld * 4, e->h_bounce, (size_t)w * 4, (size_t)w * 4, hh, hipMemcpyHostToDevice));
+    }
     return TW_OK;
 }
 tw_status down_planes(tw_engine* e, float* h, const float* d, int ld, long long ps, int w, int hh, int planes)
 {
-    for (int c = 0; c < planes; c++)
-        TW_HIP(e, hipMemcpy2D(h + (size_t)c * w * hh, (size_t)w * 4, d + c * ps, (size_t)ld * 4, (size_t)w * 4, hh,
-                              hipMemcpyDeviceToHost));
+    const size_t plane = (size_t)w * hh * 4;
+    tw_status r = bounce_reserve(e, plane);
+    if (r) return r;
+    for (int c = 0; c < planes; c++) {
+        TW_HIP(e, hipMemcpy2D(e->h_bounce, (size_t)w * 4, d + c * ps, (size_t)ld * 4, (size_t)w * 4, hh, hipMemcpyDeviceToHost));
+        memcpy(h + (size_t)c * w * hh, e->h_bounce, plane);
+    }
     return TW_OK;
 }
 }  // namespace
