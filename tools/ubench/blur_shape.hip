@@ -224,6 +224,79 @@ static void run_roll(const char* name, const float* M0, const float* R, float* M
     printf("rolling window, %-42s %8.1f us per %d pairs  %6.2f us/pair  %5.2f TB/s  (%d workgroups)\n", name, best, np, best / np,
            bpp * W * H * np / best / 1e6, (int)(grid.x * grid.y * grid.z));
 }
+// NEVER MATERIALISE M (round 4, the structural idea left): an iteration that reads the previous iteration's FLOW (8 B/px),
+// R0 and R1 (40 B/px) and recomputes M on the fly for the rows entering a rolling window, then writes the new flow (8 B/px):
+// 56 B/px instead of 80, no separate first-update launch, every launch the same.  Its memory shape, no arithmetic: a
+// workgroup of SC columns (SC - 30 of them outputs) marches NT steps of 8 rows; per step every thread handles one pixel of
+// the 8 new rows (R0, flow, the 2x2 R1 taps), then the step's 8 x (SC - 30) outputs store two flow planes.
+template <int SC, int NT>
+__global__ __launch_bounds__(SC * 8) void kfused(const float* __restrict__ R, const float* __restrict__ flin, float* __restrict__ flout,
+                                                 long long ps)
+{
+    constexpr int OUT = SC - 2 * MH;
+    const unsigned gx = gridDim.x, gy = gridDim.y, nb = gx * gy * gridDim.z;
+    unsigned b = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    const unsigned xcd = b & 7u, qq = nb >> 3, rr = nb & 7u;
+    b = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (b >> 3);
+    const int bx = (int)(b % gx), seg = (int)((b / gx) % gy), z = (int)(b / gx / gy);
+    const int tid = threadIdx.x, col = tid % SC, rw = tid / SC;  // 8 rows x SC columns per step
+    const int x = min(max(bx * OUT - MH + col, 0), W - 2);
+    const float* R0 = R + (long long)(2 * z) * 5 * ps;
+    const float* R1 = R0 + 5 * ps;
+    const float* fi = flin + (long long)z * 2 * ps;
+    float* fo = flout + (long long)z * 2 * ps;
+    const int ys = seg * NT * TH;
+    float acc = 0.f;
+    auto row_px = [&](int y) {
+        const int yc = min(max(y, 0), H - 2);
+        const long long o = (long long)yc * LD + x;
+        float s = fi[o] + fi[o + ps];
+#pragma unroll
+        for (int c = 0; c < 5; c++) {
+            s += R0[o + c * ps];
+            s += R1[o + c * ps] + R1[o + c * ps + 1] + R1[o + c * ps + LD] + R1[o + c * ps + LD + 1];
+        }
+        return s;
+    };
+    // prologue: the 30 rows above the first new block (4 rounds of 8 rows)
+    for (int i = 0; i < 2 * MH; i += 8)
+        if (i + rw < 2 * MH) acc += row_px(ys - MH + i + rw);
+#pragma unroll 1
+    for (int st = 0; st < NT; st++) {
+        const int y0 = ys + st * TH;
+        if (y0 >= H) break;
+        acc += row_px(y0 + MH + rw);
+        const int ox = bx * OUT + col - MH, oy = y0 + rw;
+        if (col >= MH && col < SC - MH && ox < W && oy < H) {
+            const long long o = (long long)oy * LD + ox;
+            fo[o] = acc;
+            fo[o + ps] = acc + 1.f;
+        }
+    }
+}
+template <int SC, int NT>
+static void run_fused(const char* name, const float* R, const float* fl, float* fl2, long long ps, int np)
+{
+    constexpr int OUT = SC - 2 * MH;
+    const int nseg = ((H + TH - 1) / TH + NT - 1) / NT;
+    const dim3 grid((W + OUT - 1) / OUT, nseg, np);
+    double best = 1e30;
+    for (int rep = 0; rep < 2; rep++) {
+        hipEvent_t a, b;
+        hipEventCreate(&a);
+        hipEventCreate(&b);
+        hipLaunchKernelGGL((kfused<SC, NT>), grid, dim3(SC * 8), 0, 0, R, fl, fl2, ps);
+        hipEventRecord(a);
+        for (int i = 0; i < 10; i++) hipLaunchKernelGGL((kfused<SC, NT>), grid, dim3(SC * 8), 0, 0, R, fl, fl2, ps);
+        hipEventRecord(b);
+        hipEventSynchronize(b);
+        float ms = 0;
+        hipEventElapsedTime(&ms, a, b);
+        best = ms * 1e3 / 10 < best ? ms * 1e3 / 10 : best;
+    }
+    printf("M never materialised, %-40s %8.1f us per %d pairs  %6.2f us/pair  %5.2f TB/s on 56 B/px  (%d workgroups of %d threads)\n",
+           name, best, np, best / np, 56.0 * W * H * np / best / 1e6, (int)(grid.x * grid.y * grid.z), SC * 8);
+}
 // window loads only, in other shapes: VEC floats per lane and load (b32 / b64 / b128: a wave then covers 64 * VEC columns),
 // ROWS output rows per tile (window = ROWS + 30 rows).  Same bytes per output row for a given ROWS.
 template <int VEC, int ROWS>
@@ -345,6 +418,14 @@ int main()
     run_roll<27, false, true>("refreshing, NT=27, 2 workgroups per CU", M0, R, M1, fl, ps, np, 65536);
     run_roll<27, false, false>("last launch, NT=27", M0, R, M1, fl, ps, np);
     run_roll<135, false, false>("last launch, NT=135", M0, R, M1, fl, ps, np);
+    float* fl2;
+    hipMalloc(&fl2, ps * 2 * np * 4);
+    hipMemset(fl, 0, ps * 2 * np * 4);
+    run_fused<128, 27>("128-column strips (98 outputs), NT=27", R, fl, fl2, ps, np);
+    run_fused<128, 15>("128-column strips (98 outputs), NT=15", R, fl, fl2, ps, np);
+    run_fused<128, 135>("128-column strips (98 outputs), NT=135", R, fl, fl2, ps, np);
+    run_fused<96, 27>("96-column strips (66 outputs), NT=27", R, fl, fl2, ps, np);
+    run_fused<64, 27>("64-column strips (34 outputs), NT=27", R, fl, fl2, ps, np);
     run_win<1, 8>("b32, 8-row tiles (as built)", M0, fl, ps, np);
     run_win<2, 8>("b64, 8-row tiles", M0, fl, ps, np);
     run_win<4, 8>("b128, 8-row tiles", M0, fl, ps, np);
