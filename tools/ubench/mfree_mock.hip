@@ -1,0 +1,214 @@
+// Performance mock of the "never materialise M" iteration (profiles/r04_m_free_iteration.md): the REAL amounts of memory
+// traffic, LDS traffic, barriers and arithmetic of such a kernel, with no care for the image borders or for the CPU's exact
+// operation order — is a persistent 16-wave workgroup per CU with a 40-row LDS ring of M anywhere near the ~37 us per launch
+// its instruction count allows?  (The replay with no arithmetic at all: 29.9 us per pair; the refreshing launch as built:
+// 42.5 us; first update 29 us; last launch 27.5 us.)
+//   per 8-row step of a 128-column strip (98 output columns), 1 024 threads:
+//     C  1 pixel of the 8 new rows per thread: R0, previous flow, 2x2 taps of R1 at x + flow, FarnebackUpdateMatrices -> ring
+//     V  (plane, column) = 640 threads: 38 ring rows -> 8 window sums -> vbuf
+//     H  (plane, row, 4-pixel group) = 1 000 units: 36-value window from vbuf -> 4 sums -> hbuf
+//     S  1 output pixel per thread (784): 2x2 solve in double, two flow stores
+//   PIPE = 1: the loads of step t + 1's C phase are issued before V(t) and its taps before H(t) (software pipeline by hand)
+// hipcc --offload-arch=gfx950 -O3 -w -ffp-contract=off
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+constexpr int W = 1920, H = 1080, LD = 1920, MH = 15, SC = 128, OUT = SC - 2 * MH, TH = 8, RING = 40, NQ = 25;
+typedef float __attribute__((ext_vector_type(4))) f4;
+struct Coef {
+    float k[16];
+};
+__device__ __forceinline__ void combine(const float q[5], const float t[5][4], float fx, float fy, float dx, float dy, float M[5])
+{
+    const float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
+    float r2 = a00 * t[0][0] + a01 * t[0][1] + a10 * t[0][2] + a11 * t[0][3];
+    float r3 = a00 * t[1][0] + a01 * t[1][1] + a10 * t[1][2] + a11 * t[1][3];
+    float r4 = a00 * t[2][0] + a01 * t[2][1] + a10 * t[2][2] + a11 * t[2][3];
+    float r5 = a00 * t[3][0] + a01 * t[3][1] + a10 * t[3][2] + a11 * t[3][3];
+    float r6 = a00 * t[4][0] + a01 * t[4][1] + a10 * t[4][2] + a11 * t[4][3];
+    r4 = (q[2] + r4) * 0.5f;
+    r5 = (q[3] + r5) * 0.5f;
+    r6 = (q[4] + r6) * 0.25f;
+    r2 = (q[0] - r2) * 0.5f;
+    r3 = (q[1] - r3) * 0.5f;
+    r2 += r4 * dy + r6 * dx;
+    r3 += r6 * dy + r5 * dx;
+    M[0] = r4 * r4 + r6 * r6;
+    M[1] = (r4 + r5) * r6;
+    M[2] = r5 * r5 + r6 * r6;
+    M[3] = r4 * r2 + r6 * r3;
+    M[4] = r6 * r2 + r5 * r3;
+}
+template <int NT, bool PIPE>
+__global__ __launch_bounds__(1024) void kmock(const float* __restrict__ R, const float* __restrict__ flin, float* __restrict__ flout,
+                                              long long ps, Coef c)
+{
+    __shared__ __attribute__((aligned(16))) float ring[5][RING][SC];
+    __shared__ __attribute__((aligned(16))) float vbuf[5][TH][SC];
+    __shared__ __attribute__((aligned(16))) float hbuf[5][TH][4 * NQ];
+    const unsigned gx = gridDim.x, gy = gridDim.y, nb = gx * gy * gridDim.z;
+    unsigned b = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    const unsigned xcd = b & 7u, qq = nb >> 3, rr = nb & 7u;
+    b = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (b >> 3);
+    const int bx = (int)(b % gx), seg = (int)((b / gx) % gy), z = (int)(b / gx / gy);
+    const int tid = threadIdx.x, col = tid & (SC - 1), rw = tid >> 7;
+    const int xg = min(max(bx * OUT - MH + col, 0), W - 2);
+    const float* R0 = R + (long long)(2 * z) * 5 * ps;
+    const float* R1 = R0 + 5 * ps;
+    const float* fi = flin + (long long)z * 2 * ps;
+    float* fo = flout + (long long)z * 2 * ps;
+    const int ys = seg * NT * TH;
+    float q[5], tp[5][4], dx = 0, dy = 0, fx = 0, fy = 0, Mv[5];
+    auto g1 = [&](int y) {  // R0 and the previous flow of one pixel
+        const long long o = (long long)min(max(y, 0), H - 2) * LD + xg;
+        dx = fi[o];
+        dy = fi[o + ps];
+#pragma unroll
+        for (int k = 0; k < 5; k++) q[k] = R0[o + k * ps];
+    };
+    auto g2 = [&](int y) {  // the taps at x + flow
+        const int yc = min(max(y, 0), H - 2);
+        const float px = (float)xg + dx, py = (float)yc + dy;
+        const float flx = floorf(px), fly = floorf(py);
+        const bool inb = flx >= 0.f && flx < (float)(W - 1) && fly >= 0.f && fly < (float)(H - 1);
+        const int x1 = inb ? (int)flx : 0, y1 = inb ? (int)fly : 0;
+        fx = px - (float)x1;
+        fy = py - (float)y1;
+        const float* p = R1 + (long long)y1 * LD + x1;
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            tp[k][0] = p[k * ps];
+            tp[k][1] = p[k * ps + 1];
+            tp[k][2] = p[k * ps + LD];
+            tp[k][3] = p[k * ps + LD + 1];
+        }
+    };
+    // prologue: rows ys - 15 .. ys + 14 into ring blocks (30 rows = 4 rounds of 8, the last one partial)
+    for (int i = 0; i < 32; i += 8) {
+        const int y = ys - MH + i + rw;
+        g1(y);
+        g2(y);
+        combine(q, tp, fx, fy, dx, dy, Mv);
+        const int slot = ((i + rw) + RING) % RING;
+#pragma unroll
+        for (int k = 0; k < 5; k++) ring[k][slot][col] = Mv[k];
+    }
+    int base = 32;  // ring slot where the next new block goes (rows ys - 15 + base ...); window of step t starts at slot 8 t
+    if (PIPE) {
+        g1(ys - MH + base + rw);
+        g2(ys - MH + base + rw);
+    }
+#pragma unroll 1
+    for (int st = 0; st < NT; st++) {
+        const int y0 = ys + st * TH;
+        if (y0 >= H) break;
+        // C: the new rows y0 + 17 .. y0 + 24 of this mock's bookkeeping (8 rows below what the ring holds)
+        if (!PIPE) {
+            g1(ys - MH + base + rw);
+            g2(ys - MH + base + rw);
+        }
+        combine(q, tp, fx, fy, dx, dy, Mv);
+        {
+            const int slot = (base + rw) % RING;
+#pragma unroll
+            for (int k = 0; k < 5; k++) ring[k][slot][col] = Mv[k];
+        }
+        base += 8;
+        if (PIPE) g1(ys - MH + base + rw);  // next step's R0 / flow fly under the vertical pass
+        __syncthreads();
+        // V: 38-row window starting at ring row 8 st
+        if (tid < 5 * SC) {
+            const int pl = tid >> 7;
+            float wv[TH + 2 * MH];
+#pragma unroll
+            for (int i = 0; i < TH + 2 * MH; i++) wv[i] = ring[pl][(8 * st + i) % RING][col];
+#pragma unroll
+            for (int r = 0; r < TH; r++) {
+                float s0 = wv[r + MH] * c.k[0];
+#pragma unroll
+                for (int i = 1; i <= MH; i++) s0 += (wv[r + MH + i] + wv[r + MH - i]) * c.k[i];
+                vbuf[pl][r][col] = s0;
+            }
+        }
+        if (PIPE) g2(ys - MH + base + rw);  // next step's taps fly under the horizontal pass and the solve
+        __syncthreads();
+        // H: (plane, row, group)
+        if (tid < 5 * TH * NQ) {
+            const int pl = tid / (TH * NQ), it = tid - pl * (TH * NQ), r = it / NQ, g = it - r * NQ;
+            float v[36];
+#pragma unroll
+            for (int u = 0; u < 9; u++) {
+                const f4 A = *(const f4*)&vbuf[pl][r][min(4 * g + 4 * u, SC - 4)];
+                v[4 * u] = A[0];
+                v[4 * u + 1] = A[1];
+                v[4 * u + 2] = A[2];
+                v[4 * u + 3] = A[3];
+            }
+            f4 o;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                float sum = v[16 + j] * c.k[0];
+#pragma unroll
+                for (int i = 1; i <= MH; i++) sum += c.k[i] * (v[16 + j - i] + v[16 + j + i]);
+                o[j] = sum;
+            }
+            *(f4*)&hbuf[pl][r][4 * g] = o;
+        }
+        __syncthreads();
+        // S
+        if (tid < TH * OUT) {
+            const int r = tid / OUT, cx = tid - r * OUT;
+            const double g11 = hbuf[0][r][cx], g12 = hbuf[1][r][cx], g22 = hbuf[2][r][cx], h1 = hbuf[3][r][cx], h2 = hbuf[4][r][cx];
+            const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
+            const int ox = bx * OUT + cx, oy = y0 + r;
+            if (ox < W && oy < H) {
+                const long long o = (long long)oy * LD + ox;
+                fo[o] = (float)((g11 * h2 - g12 * h1) * idet);
+                fo[o + ps] = (float)((g22 * h1 - g12 * h2) * idet);
+            }
+        }
+        // (no barrier: the next step's ring write goes to the block the vertical pass of THIS step no longer reads —
+        // RING = 40 = the 38-row window + ... in this mock the block written is 8 rows ahead; the barrier after C orders it)
+    }
+}
+template <int NT, bool PIPE>
+static void run(const char* name, const float* R, const float* fl, float* fl2, long long ps, int np)
+{
+    const int nseg = ((H + TH - 1) / TH + NT - 1) / NT;
+    const dim3 grid((W + OUT - 1) / OUT, nseg, np);
+    Coef c;
+    for (int i = 0; i < 16; i++) c.k[i] = 0.05f / (1 + i);
+    double best = 1e30;
+    for (int rep = 0; rep < 2; rep++) {
+        hipEvent_t a, b;
+        hipEventCreate(&a);
+        hipEventCreate(&b);
+        hipLaunchKernelGGL((kmock<NT, PIPE>), grid, dim3(1024), 0, 0, R, fl, fl2, ps, c);
+        hipEventRecord(a);
+        for (int i = 0; i < 5; i++) hipLaunchKernelGGL((kmock<NT, PIPE>), grid, dim3(1024), 0, 0, R, fl, fl2, ps, c);
+        hipEventRecord(b);
+        hipEventSynchronize(b);
+        float ms = 0;
+        hipEventElapsedTime(&ms, a, b);
+        best = ms * 1e3 / 5 < best ? ms * 1e3 / 5 : best;
+    }
+    hipError_t e = hipGetLastError();
+    printf("M-free iteration mock, %-34s %8.1f us per %d pairs  %6.2f us/pair  (%d workgroups; %s)\n", name, best, np, best / np,
+           (int)(grid.x * grid.y * grid.z), hipGetErrorString(e));
+}
+int main()
+{
+    const int np = 64;
+    const long long ps = (long long)LD * H;
+    float *R, *fl, *fl2;
+    hipMalloc(&R, ps * 10 * np * 4 + 65536);
+    hipMalloc(&fl, ps * 2 * np * 4);
+    hipMalloc(&fl2, ps * 2 * np * 4);
+    hipMemset(R, 0, ps * 10 * np * 4 + 65536);
+    hipMemset(fl, 0, ps * 2 * np * 4);
+    run<27, false>("27 steps per workgroup", R, fl, fl2, ps, np);
+    run<27, true>("27 steps, pipelined gathers", R, fl, fl2, ps, np);
+    run<15, true>("15 steps, pipelined gathers", R, fl, fl2, ps, np);
+    run<45, true>("45 steps, pipelined gathers", R, fl, fl2, ps, np);
+    run<135, true>("135 steps, pipelined gathers", R, fl, fl2, ps, np);
+    return 0;
+}
