@@ -94,6 +94,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="no per-kernel hipEvents in the timed region")
     ap.add_argument("--cpu-pairs", type=int, default=0, help="pairs in the CPU sample (0: two per thread)")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not run the two rocprofv3 PMC passes that measure roofline.traffic in this run (N = 1, with "
+                         "the extras); the static profiles/traffic_latest.json is used instead")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the untimed extra steps (kernel breakdown, other configs): a profiler trace then "
                          "holds only the warm-up and the timed launches")
@@ -198,6 +201,43 @@ def queue_sharded(host_pairs, devices, pairs, per_device=1, batch=128):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def live_traffic(mode, timeout=300):
+    """HBM traffic of the level-0 launches measured BY THIS RUN: two rocprofv3 PMC passes
+    (FETCH_SIZE, WRITE_SIZE; kernel trace only, never combined with other tracing) over a one-step child run of this very
+    script, rendered by tools/pmc_traffic.py with MI355X_MICROARCH.md's gfx950 corrections.  None when rocprofv3 is not on
+    the box or a pass fails (the static file of profiles/ is used then, and says so)."""
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None
+    d = tempfile.mkdtemp(prefix="twpmc_", dir="/tmp")
+    try:
+        env = dict(os.environ, TMPDIR="/tmp")
+        for c in ("FETCH_SIZE", "WRITE_SIZE"):
+            cmd = [exe, "--kernel-trace", "--pmc", c, "--output-format", "csv", "-d", os.path.join(d, c), "-o", "run", "--",
+                   sys.executable, os.path.abspath(__file__), "--mode", mode, "--steps", "1", "--warmup", "1", "--batch", "128",
+                   "--no-cpu-baseline", "--no-prof", "--no-extras"]
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd="/tmp", env=env)
+            if r.returncode != 0:
+                return None
+        out = os.path.join(d, "traffic.json")
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_traffic.py"), os.path.join(d, "FETCH_SIZE"),
+                            os.path.join(d, "WRITE_SIZE"), out], capture_output=True, text=True, timeout=120,
+                           env=dict(env, TW_GIT_COMMIT=os.environ.get("TW_GIT_COMMIT", "this run")))
+        if r.returncode != 0 or not os.path.exists(out):
+            return None
+        t = json.load(open(out))
+        if not t.get("tw_blur_solve") or not t.get("tw_polyexp"):
+            return None
+        t["_provenance"]["source"] = "live: PMC passes run by this bench.py invocation (child runs of --mode %s --steps 1 --batch 128)" % mode
+        t["_provenance"]["command"] = ("rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py "
+                                       "--mode %s --steps 1 --warmup 1 --batch 128 --no-cpu-baseline --no-prof --no-extras" % mode)
+        return t
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def load_traffic():
     tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
     if os.path.exists(tpath):
@@ -222,9 +262,13 @@ def roofline_obj(name, ms, launches, bytes_total, pairs_per_launch, traffic, chu
     return {"kernel": name + " @level0 (1920x1080)", "bound": "hbm", "achieved": round(gbs, 1),
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
             "traffic": tr_bytes, "traffic_pairs_per_launch": tr_pairs,
-            "traffic_source": "profiles/traffic_latest.json (static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
-                              "passes of an earlier run of this command, not a live counter; measured on launches "
-                              "of traffic_pairs_per_launch pairs and scaled to this run's pairs per launch)",
+            "traffic_source": ("live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes run by this bench.py invocation on a "
+                               "one-step child run of itself (launches of traffic_pairs_per_launch pairs, scaled to this "
+                               "run's pairs per launch)")
+            if (traffic.get("_provenance") or {}).get("source", "").startswith("live")
+            else ("profiles/traffic_latest.json (static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                  "passes of an earlier run of this command, not a live counter; measured on launches "
+                  "of traffic_pairs_per_launch pairs and scaled to this run's pairs per launch)"),
             "traffic_measured": traffic.get("_provenance"),
             "bytes_model": "what the kernel as built must move per launch (blur+solve: 80 B/px for a launch "
                            "fused with the matrix refresh, 28 B/px for the last one; polyexp 24 B/px)",
@@ -745,7 +789,11 @@ def main():
             del src, dst
         except Exception:
             copy_gbs = None
-        traffic = load_traffic()
+        traffic = None
+        if world == 1 and not args.no_extras and not args.no_live_traffic and not args.no_prof:
+            traffic = live_traffic(args.mode)  # ~1 minute: two counter passes over a one-step child run
+        if traffic is None:
+            traffic = load_traffic()
 
         def roof(kc):
             if kc not in prof or prof[kc][1] == 0:
