@@ -209,6 +209,10 @@ def live_traffic(mode, timeout=300):
     exe = shutil.which("rocprofv3")
     if not exe:
         return None
+    # never nested: when this run is itself being profiled (rocprofv3 -- python3 bench.py) its children would inherit the
+    # profiler's preload and environment
+    if "rocprofiler" in os.environ.get("LD_PRELOAD", "") or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
+        return None
     d = tempfile.mkdtemp(prefix="twpmc_", dir="/tmp")
     try:
         env = dict(os.environ, TMPDIR="/tmp")
