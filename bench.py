@@ -809,8 +809,16 @@ def main():
             per_pair_launches = 3 if kc == twflow.K_BLUR_SOLVE else 1
             pairs_mine = args.batch * args.steps
             bytes_total = eng.algorithmic_bytes(kc, 0, W, H) * per_pair_launches * pairs_mine
-            return roofline_obj(twflow.KERNEL_NAMES[kc], ms, n, bytes_total, per_pair_launches * pairs_mine / n,
-                                traffic, chunk=eng.level_chunk(W, H, 0))
+            rf = roofline_obj(twflow.KERNEL_NAMES[kc], ms, n, bytes_total, per_pair_launches * pairs_mine / n,
+                              traffic, chunk=eng.level_chunk(W, H, 0))
+            if rf and kc == twflow.K_BLUR_SOLVE:
+                # the same launches priced on SURVEY 8(d)'s STAGE model instead of the as-built bytes: a refreshing launch
+                # does the work of blur5+solve (28 B/px) AND of updateMatrices (68 B/px); the last one is 28 B/px
+                survey = (2 * (28 + 68) + 28) * float(W * H) * pairs_mine
+                rf["frac_survey_stage_model"] = round(survey / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                rf["survey_stage_model_note"] = ("SURVEY 8(d) prices the stages a fused launch replaces at (2 x 96 + 28) / 3 = "
+                                                 "73.3 B/px per launch; `frac` uses the 62.7 B/px the fused kernels actually move")
+            return rf
 
         line = {
             "metric": METRIC,
