@@ -66,6 +66,7 @@ tw_status tw_host_free(tw_engine*, void* hptr)
     free(hptr);
     return TW_OK;
 }
+tw_status tw_set_option(tw_engine*, int, int) { return TW_OK; }
 tw_status tw_prof_select(tw_engine*, int, int) { return TW_OK; }
 tw_status tw_prof_read(tw_engine*, int, double* ms, int* n)
 {

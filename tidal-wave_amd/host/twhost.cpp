@@ -756,6 +756,13 @@ void Consumer::run()
     } else {
         eng_err = "no HIP device available";
     }
+    // Opt-in (TW_SCAN_FUSED_FINAL=1): the engine option that evaluates the last level-0 iteration at the span-grid points
+    // only.  A consumer hands back vectors, never the flow field, so the option is invisible to the caller (bit-identical
+    // vectors, tests/test_gpu_parity.py::test_scan_fused_final_iteration_option) and worth +3-5 % of GPU throughput; it
+    // stays off by default because the reference's consumer computes the whole field (src/consumer.cpp:54).
+    if (eng)
+        if (const char* ev = getenv("TW_SCAN_FUSED_FINAL"))
+            if (atoi(ev) != 0) (void)tw_set_option(eng, TW_OPT_SCAN_FUSED_FINAL, 1);
     const bool prof = eng && shared_ && shared_->profile;
     if (prof) {
         (void)tw_prof_select(eng, TW_K_BLUR_SOLVE, 0);
