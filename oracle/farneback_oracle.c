@@ -672,6 +672,82 @@ int orc_farneback(const uint8_t* prev0, const uint8_t* next0, int w0, int h0, co
     return 0;
 }
 
+/* ---- cv::resize on CV_8UC1 as called at /root/reference/src/opticalflow.cpp:64-68 -----------------
+ * `cv::resize(targetImg, resized, resized.size(), cv::INTER_NEAREST)`: the constant 0 lands in the
+ * `fx` parameter; dsize is non-empty, so the scale comes from dsize and the interpolation is the
+ * default INTER_LINEAR.  OpenCV 2.4.9 imgproc/imgwarp.cpp, depth CV_8U
+ * ("fixpt"), restated per OUTPUT PIXEL (no row cache, no coefficient tables shared with any other
+ * implementation in this repository):
+ *   - cv::resize: scale = 1/((double)dsize/ssize); an exact 2 x 2 reduction is switched to
+ *     INTER_AREA (ResizeAreaFast_Invoker<uchar,int>: (S00+S01+S10+S11+2)>>2);
+ *   - coordinate rule: f = (float)((d+0.5)*scale-0.5); s = cvFloor(f); f -= s; in x only: s<0 ->
+ *     (0, f=0), s>=ssize-1 -> (ssize-1, f=0); in y the rows are clipped later, the weights are not;
+ *   - coefficients: saturate_cast<short>(w * INTER_RESIZE_COEF_SCALE) with INTER_RESIZE_COEF_SCALE =
+ *     1<<11, w in {1.f-f, f} (float product, cvRound = round-half-even);
+ *   - HResizeLinear<uchar,int,short,2048>: D = S[sx]*a0 + S[sx+1]*a1 while sx+1 < ssize.width
+ *     (dx < xmax), D = S[sx]*2048 beyond;
+ *   - VResizeLinear<uchar,int,short,FixedPtCast<int,uchar,22>>:
+ *     dst = uchar((((b0*(S0>>4))>>16) + ((b1*(S1>>4))>>16) + 2) >> 2), rows sy and sy+1 clipped to
+ *     [0, ssize.height) (resizeGeneric_Invoker's clip()).
+ * Parity unpinned: no fixture of the reference has a pair of unequal sizes.                        */
+static short orc_sat_short(float v)
+{
+    int r = cv_round((double)v);
+    return (short)(r < -32768 ? -32768 : (r > 32767 ? 32767 : r));
+}
+static int orc_clip(int x, int a, int b) { return x >= a ? (x < b ? x : b - 1) : a; }
+/* one horizontally interpolated sample of source row `row` (already clipped), in 11-bit fixed point */
+static int orc_hsample_u8(const uint8_t* src, int sw, int row, int dx, double scale_x)
+{
+    float fx = (float)((dx + 0.5) * scale_x - 0.5);
+    int sx = cv_floor(fx);
+    fx -= sx;
+    if (sx < 0) { fx = 0; sx = 0; }
+    if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+    const uint8_t* S = src + (size_t)row * sw;
+    if (sx + 1 >= sw) return S[sx] * 2048; /* dx >= xmax */
+    float c0 = 1.f - fx, c1 = fx;
+    return S[sx] * orc_sat_short(c0 * 2048) + S[sx + 1] * orc_sat_short(c1 * 2048);
+}
+void orc_resize_u8_linear(const uint8_t* src, int sw, int sh, uint8_t* dst, int dw, int dh)
+{
+    double inv_scale_x = (double)dw / sw, inv_scale_y = (double)dh / sh;
+    double scale_x = 1. / inv_scale_x, scale_y = 1. / inv_scale_y;
+    int iscale_x = (int)lrint(scale_x), iscale_y = (int)lrint(scale_y); /* saturate_cast<int>(double) = cvRound */
+    int is_area_fast = fabs(scale_x - iscale_x) < DBL_EPSILON && fabs(scale_y - iscale_y) < DBL_EPSILON;
+    if (is_area_fast && iscale_x == 2 && iscale_y == 2) {
+        for (int dy = 0; dy < dh; dy++)
+            for (int dx = 0; dx < dw; dx++) {
+                const uint8_t* S = src + (size_t)(2 * dy) * sw + 2 * dx;
+                dst[(size_t)dy * dw + dx] = (uint8_t)((S[0] + S[1] + S[sw] + S[sw + 1] + 2) >> 2);
+            }
+        return;
+    }
+    for (int dy = 0; dy < dh; dy++) {
+        float fy = (float)((dy + 0.5) * scale_y - 0.5);
+        int sy = cv_floor(fy);
+        fy -= sy;
+        short b0 = orc_sat_short((1.f - fy) * 2048), b1 = orc_sat_short(fy * 2048);
+        int r0 = orc_clip(sy, 0, sh), r1 = orc_clip(sy + 1, 0, sh);
+        for (int dx = 0; dx < dw; dx++) {
+            int S0 = orc_hsample_u8(src, sw, r0, dx, scale_x);
+            int S1 = orc_hsample_u8(src, sw, r1, dx, scale_x);
+            dst[(size_t)dy * dw + dx] = (uint8_t)((((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2);
+        }
+    }
+}
+
+/* OpticalFlow::calculate's size rule (/root/reference/src/opticalflow.cpp:52-68) on decoded gray images:
+ * returns 3 (DontMatchSize) when either dimension differs by more than 5, else 0 with `target_out`
+ * (ew x eh) = the target as calculateInternal receives it (a copy when the sizes are equal).       */
+int orc_reconcile_target(const uint8_t* target, int tw, int th, int ew, int eh, uint8_t* target_out)
+{
+    if (abs(eh - th) > 5 || abs(ew - tw) > 5) return 3;
+    if (eh != th || ew != tw) orc_resize_u8_linear(target, tw, th, target_out, ew, eh);
+    else memcpy(target_out, target, (size_t)ew * eh);
+    return 0;
+}
+
 /* ---- span-grid threshold scan (src/consumer.cpp:60-76) ------------------------------------ */
 int orc_span_scan(const float* flowx, const float* flowy, int w, int h, int span, double threshold, orc_vector* out,
                   int cap)

@@ -45,6 +45,9 @@ void orc_update_flow_box(const float* R0, const float* R1, float* flow_c2, float
 void orc_flow_upsample(const float* prev_c2, int pw, int ph, float* flow_c2, int w, int h, double pyr_scale);
 int orc_farneback(const uint8_t* prev, const uint8_t* next, int w, int h, const orc_params* p, float* flowx,
                   float* flowy);
+/* /root/reference/src/opticalflow.cpp:52-68 (the <= 5 px size reconcile: 8-bit INTER_LINEAR resize of the target) */
+void orc_resize_u8_linear(const uint8_t* src, int sw, int sh, uint8_t* dst, int dw, int dh);
+int orc_reconcile_target(const uint8_t* target, int tw, int th, int ew, int eh, uint8_t* target_out);
 int orc_span_scan(const float* flowx, const float* flowy, int w, int h, int span, double threshold, orc_vector* out,
                   int cap);
 

@@ -68,6 +68,10 @@ def lib():
         L.orc_flow_upsample.argtypes = [fp, C.c_int, C.c_int, fp, C.c_int, C.c_int, C.c_double]
         L.orc_farneback.argtypes = [u8p, u8p, C.c_int, C.c_int, C.POINTER(Params), fp, fp]
         L.orc_farneback.restype = C.c_int
+        L.orc_resize_u8_linear.argtypes = [u8p, C.c_int, C.c_int, u8p, C.c_int, C.c_int]
+        L.orc_resize_u8_linear.restype = None
+        L.orc_reconcile_target.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int, u8p]
+        L.orc_reconcile_target.restype = C.c_int
         L.orc_span_scan.argtypes = [fp, fp, C.c_int, C.c_int, C.c_int, C.c_double, C.POINTER(Vector), C.c_int]
         L.orc_span_scan.restype = C.c_int
         _lib = L
@@ -171,6 +175,24 @@ def farneback(prev, nxt, params=None):
     if rc != 0:
         raise ValueError("orc_farneback rc=%d" % rc)
     return fx, fy
+
+
+def resize_u8_linear(img, dw, dh):
+    """cv::resize(img, dsize=(dw, dh)) on CV_8UC1, INTER_LINEAR (src/opticalflow.cpp:66)."""
+    img = np.ascontiguousarray(img, np.uint8)
+    sh, sw = img.shape
+    out = np.empty((dh, dw), np.uint8)
+    lib().orc_resize_u8_linear(_u8(img), sw, sh, _u8(out), dw, dh)
+    return out
+
+
+def reconcile_target(target, ew, eh):
+    """src/opticalflow.cpp:52-68: None when the sizes differ by more than 5 px, else the target at (eh, ew)."""
+    target = np.ascontiguousarray(target, np.uint8)
+    th, tw = target.shape
+    out = np.empty((eh, ew), np.uint8)
+    rc = lib().orc_reconcile_target(_u8(target), tw, th, ew, eh, _u8(out))
+    return None if rc else out
 
 
 def span_scan(fx, fy, span=10, threshold=5.0):

@@ -340,23 +340,31 @@ jobs.forEach(function(j){t.calc(j[0],j[1]);});
 def test_size_reconcile_within_five_pixels(tmp_path):
     """src/opticalflow.cpp:52-68: sizes that differ by at most 5 px are reconciled (the target is resized to the
     expected image's size, dims of the response are the expected image's); more than 5 px is "Don't match image
-    size".  The 8-bit bilinear resize itself is parity-unpinned (no fixture of the reference exercises it)."""
+    size".  VALUE-level: every response's status and vector list equal
+    oracle(orc_reconcile_target -> orc_farneback -> orc_span_scan) on the decoded gray images — the product's
+    resize (host/twhost.cpp resize_u8_linear) against the oracle's independent restatement, through node + the GPU.
+    Parity unpinned (no fixture of the reference has unequal sizes)."""
     Image = pytest.importorskip("PIL.Image")
+    sys_path_oracle()
+    import oracle as O
     rng = np.random.default_rng(3)
     yy, xx = np.mgrid[0:90, 0:120]
-    a = ((np.sin(xx / 7.0) + np.cos(yy / 5.0)) * 60 + 128).astype(np.uint8)
+    a = ((np.sin(xx / 7.0) + np.cos(yy / 5.0)) * 60 + 128 + rng.integers(-6, 7, (90, 120))).clip(0, 255).astype(np.uint8)
     pa = tmp_path / "e.png"
     Image.fromarray(a).save(pa)
-    out = []
-    for k, (dh, dw) in enumerate([(0, 0), (3, -2), (-5, 5), (6, 0), (0, -6)]):
-        b = np.asarray(Image.fromarray(a).resize((120 + dw, 90 + dh), Image.BILINEAR))
+    out, targets = [], {}
+    offsets = [(0, 0), (3, -2), (-5, 5), (6, 0), (0, -6), (5, 5), (-5, -5), (1, 0), (0, -1), (-4, 3)]
+    for k, (dh, dw) in enumerate(offsets):
+        b = np.asarray(Image.fromarray(a).resize((120 + dw, 90 + dh), Image.BILINEAR)).copy()
+        b[20:40, 30:70] = np.roll(b[20:40, 30:70], 3, axis=1)  # something that moves: a non-empty vector list
         pb = tmp_path / ("t%d.png" % k)
         Image.fromarray(b).save(pb)
         out.append(str(pb))
+        targets[str(pb)] = b
     r = node("""
-var T=require('./index'); var t=new T.TidalWave({}); var res=[]; var n=0; var targets=process.argv.slice(2);
+var T=require('./index'); var t=new T.TidalWave({span:6, threshold:0.25}); var res=[]; var n=0; var targets=process.argv.slice(2);
 function done(){ if(++n===targets.length) t.dispose(); }
-t.on('data',function(d){res.push({t:d.target_image,h:d.height,w:d.width,s:d.status}); done();});
+t.on('data',function(d){res.push({t:d.target_image,h:d.height,w:d.width,s:d.status,v:d.vector}); done();});
 t.on('error',function(e){res.push({e:e.reason}); done();});
 t.on('finish',function(){console.log(JSON.stringify(res));});
 targets.forEach(function(p){t.calc(process.argv[1],p);});
@@ -365,7 +373,15 @@ targets.forEach(function(p){t.calc(process.argv[1],p);});
     res = json.loads(r.stdout.strip().splitlines()[-1])
     data = [x for x in res if "t" in x]
     errs = [x for x in res if "e" in x]
-    assert len(data) == 3 and all((d["h"], d["w"]) == (90, 120) for d in data)
+    assert len(data) == len(offsets) - 2 and all((d["h"], d["w"]) == (90, 120) for d in data)
     assert sorted(e["e"] for e in errs) == ["Don't match image size"] * 2
-    same = [d for d in data if d["t"] == out[0]][0]
-    assert same["s"] == "OK"
+    nonempty = 0
+    for d in data:
+        b = O.reconcile_target(targets[d["t"]], 120, 90)
+        assert b is not None
+        wx, wy = O.farneback(a, b)
+        want = O.span_scan(wx, wy, 6, 0.25)
+        assert d["s"] == ("SUSPICIOUS" if want else "OK"), d["t"]
+        assert [(v["x"], v["y"], v["dx"], v["dy"]) for v in d["v"]] == [tuple(v) for v in want], d["t"]
+        nonempty += bool(want)
+    assert nonempty >= 6, "the check is vacuous without vectors"

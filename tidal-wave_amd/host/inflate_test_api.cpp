@@ -58,6 +58,13 @@ int twt_finish_rows(const uint8_t* rows, size_t n, int w, int h, int ch, uint8_t
     memcpy(out, g.data(), g.size());
     return 1;
 }
+// resize_u8_linear (the <= 5 px size reconcile of prepare(), src/opticalflow.cpp:64-68): dw * dh bytes into out
+void twt_resize_u8(const uint8_t* src, int sw, int sh, uint8_t* out, int dw, int dh)
+{
+    std::vector<uint8_t> s(src, src + (size_t)sw * sh), d;
+    twhost::resize_u8_linear(s, sw, sh, d, dw, dh);
+    memcpy(out, d.data(), (size_t)dw * dh);
+}
 // the same inflate-heavy loop a mutation fuzzer wants, inside the sanitised library: `iters` mutations of one zlib
 // stream, each decoded into a buffer of exactly `cap` bytes; returns how many were accepted
 long twt_fuzz_stream(const uint8_t* s, size_t n, size_t cap, int iters, unsigned seed)
