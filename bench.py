@@ -742,14 +742,15 @@ def main():
     if world == 1 and not args.no_extras:
         nf = max(2, args.steps // 2)
         if pinned_mode:
+            nf_res = max(2, args.steps)  # the resident figure over the SAME number of steps as the headline
             source["pinned"] = False
             if not args.no_prof:
                 eng.prof_select(twflow.K_BLUR_SOLVE, 0)
-            r_rate = timed_rate(nf)
+            r_rate = timed_rate(nf_res)
             r_prof = eng.prof_read(twflow.K_BLUR_SOLVE) if not args.no_prof else (0.0, 0)
             eng.prof_select(-1, -2)
             source["pinned"] = True
-            resident_extra = {"pairs_per_s": round(r_rate, 2), "steps": nf, "blur_ms_launches": r_prof}
+            resident_extra = {"pairs_per_s": round(r_rate, 2), "steps": nf_res, "blur_ms_launches": r_prof}
         # what the synthetic mix is worth — the flow-dependent R1 gather's locality follows the flow field
         sensitivity = {}
         base_dev = source["dev"]
@@ -776,21 +777,11 @@ def main():
         bytes_pair = eng.algorithmic_bytes_pair(W, H, SPAN)
         min_pair = eng.min_traffic_bytes_pair(W, H, SPAN)
         # measured device copy rate of this GPU in this run (report it beside the 8 TB/s nominal peak):
-        # 1 GiB torch copy, read + write counted, outside the timed region
+        # 10 launches of a float4 HIP copy kernel over 1 GiB on the engine's stream (tw_debug_copy_rate: the shape
+        # MI355X_MICROARCH.md quotes 6.29 TB/s for), read + write counted, outside the timed region
         copy_gbs = None
         try:
-            src = torch.empty(1 << 30, dtype=torch.uint8, device=torch.device("cuda", dev_index))
-            dst = torch.empty_like(src)
-            dst.copy_(src)
-            torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(10):
-                dst.copy_(src)
-            e1.record()
-            torch.cuda.synchronize()
-            copy_gbs = round(2 * 10 * (1 << 30) / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
-            del src, dst
+            copy_gbs = round(eng.copy_rate_gbps(1 << 30, 10), 1)
         except Exception:
             copy_gbs = None
         traffic = None
@@ -843,6 +834,9 @@ def main():
                                                               "N-device shape, not a scaling point" % (world, ndev),
                        "single_pair_latency_ms": round(float(np.median(lat)) * 1e3, 4)},
             "measured_copy_GBps": copy_gbs,
+            # rounds 1-3's `value` was --mode resident (pairs already in HBM); since round 4 it is --mode pinned
+            # (uploads inside the timed region).  The resident-equivalent of this run is `resident_hbm.pairs_per_s`.
+            "comparable_to_rounds_1_3": not pinned_mode,
             "pair_roofline": {"algorithmic_bytes_per_pair": bytes_pair,
                               "achieved_GBps_per_gpu": round(bytes_pair * value / world / 1e9, 1),
                               "frac_of_8TBps": round(bytes_pair * value / world / 1e9 / HBM_PEAK_GBS, 4),

@@ -169,7 +169,13 @@ tw_status tw_set_option(tw_engine* e, int option, int value);
  * tw_host_unregister on a tw_host_alloc block, answers TW_E_BAD_PARAMETER and releases nothing. */
 tw_status tw_host_alloc(tw_engine* e, size_t bytes, void** hptr);
 tw_status tw_host_free(tw_engine* e, void* hptr);
-/* Page-lock / release memory the caller owns (hipHostRegister / hipHostUnregister + the table above). */
+/* Page-lock / release memory the caller owns (hipHostRegister / hipHostUnregister + the table above).
+ * WHOLE PAGES ONLY: `hptr` must be page-aligned and `bytes` a multiple of the page size (sysconf(_SC_PAGESIZE)),
+ * i.e. memory the caller owns page-wise — mmap, aligned_alloc(page, n * page), posix_memalign.  Anything else
+ * (a malloc / new block, a cv::Mat's heap buffer) answers TW_E_BAD_PARAMETER with a tw_last_error text and
+ * page-locks nothing: a partial page is shared with the allocator's other blocks, and page-locking / releasing it
+ * next to them is what a GPU memory-access fault of round 4 traced to.  Use tw_host_alloc for
+ * buffers that need not live at a given address. */
 tw_status tw_host_register(tw_engine* e, void* hptr, size_t bytes);
 tw_status tw_host_unregister(tw_engine* e, void* hptr);
 

@@ -533,7 +533,9 @@ def test_page_lock_table_is_process_wide_and_never_stale(twflow, oracle):
         mm = mmap.mmap(-1, (2 * a.size + 4095) // 4096 * 4096)
         buf = np.frombuffer(mm, np.uint8, 2 * a.size).reshape((2,) + a.shape)
         buf[0], buf[1] = a, b
-        assert L.tw_host_register(e1._h, C.c_void_p(buf.ctypes.data), buf.nbytes) == twflow.TW_OK
+        # (whole pages only: tw_host_register refuses a range that is not page-aligned / a page multiple — round 5)
+        assert L.tw_host_register(e1._h, C.c_void_p(buf.ctypes.data), buf.nbytes) == twflow.TW_E_BAD_PARAMETER
+        assert L.tw_host_register(e1._h, C.c_void_p(buf.ctypes.data), len(mm)) == twflow.TW_OK
         assert e1.wait(e1.submit(buf[0], buf[1], 10, 1.0))["vector"] == want
         assert e2.wait(e2.submit(buf[0], buf[1], 10, 1.0))["vector"] == want
         # a block is released the way it was made: tw_host_free on a registered block must not reach
@@ -549,6 +551,51 @@ def test_page_lock_table_is_process_wide_and_never_stale(twflow, oracle):
         t = e1.submit(buf[0], buf[1], 10, 1.0)
         ux, uy = oracle.farneback(buf[0], buf[1])
         assert e1.wait(t)["vector"] == oracle.span_scan(ux, uy, 10, 1.0)
+
+
+def test_host_register_takes_whole_pages_only_then_overflow_records_after_a_register_cycle(twflow, oracle):
+    """Round 4's GPU fault (a memory-access fault on a malloc-heap address inside a synchronous copy, right after a
+    hipHostRegister / hipHostUnregister cycle of a neighbouring non-page-aligned heap block) closed at the API:
+    tw_host_register REFUSES a range that is not page-aligned and a page multiple (a numpy / malloc heap block is the
+    expected refusal, with a tw_last_error text), and every pageable hand-off — here tw_wait's overflow records, > 1 024
+    hits into a plain heap array — goes through the engine's page-locked bounce buffer.  Run ONCE per suite."""
+    import ctypes as C
+    import mmap
+    rng = np.random.default_rng(78)
+    a = rand_img(rng, 120, 160)
+    b = np.roll(a, 3, axis=1)
+    wx, wy = oracle.farneback(a, b)
+    want = oracle.span_scan(wx, wy, 1, 0.25)
+    assert len(want) > 1024
+    L = twflow.lib()
+    page = mmap.PAGESIZE
+    with twflow.Engine(0, twflow.default_params(), slots=1) as e:
+        heap = np.empty(2 * a.size + 64, np.uint8)  # the malloc heap: neither aligned nor a page multiple
+        for ptr, n in [(heap.ctypes.data | 8, 2 * a.size), (heap.ctypes.data + 16, page),
+                       ((heap.ctypes.data + page - 1) // page * page, 100)]:
+            assert L.tw_host_register(e._h, C.c_void_p(ptr), n) == twflow.TW_E_BAD_PARAMETER
+            assert b"whole number of pages" in L.tw_last_error(e._h)
+        # the unregistered heap block still works as an input (staged), and the refusals pinned nothing
+        heap2 = heap[:2 * a.size].reshape((2,) + a.shape)
+        heap2[0], heap2[1] = a, b
+        assert e.diff(heap2[0], heap2[1], 1, 0.25)["vector"] == want
+        # a register / unregister cycle of pages the caller owns, then pageable traffic right beside it on the heap:
+        # tw_wait with more than HOST_RECS hits (overflow records -> bounce buffer), tw_dev_upload from the heap,
+        # a dense flow into heap planes
+        mm = mmap.mmap(-1, (2 * a.size + page - 1) // page * page)
+        buf = np.frombuffer(mm, np.uint8, 2 * a.size).reshape((2,) + a.shape)
+        buf[0], buf[1] = a, b
+        nbytes = (buf.nbytes + page - 1) // page * page
+        for _ in range(3):
+            assert L.tw_host_register(e._h, C.c_void_p(buf.ctypes.data), nbytes) == twflow.TW_OK
+            assert e.diff(buf[0], buf[1], 1, 0.25)["vector"] == want
+            assert L.tw_host_unregister(e._h, C.c_void_p(buf.ctypes.data)) == twflow.TW_OK
+            assert e.diff(heap2[0], heap2[1], 1, 0.25)["vector"] == want
+            gx, gy, _ = e.calculate_internal(heap2[0], heap2[1])
+            assert_same(gx, wx, "flowx after a register cycle")
+            assert_same(gy, wy, "flowy after a register cycle")
+        del buf
+        mm.close()
 
 
 def test_strided_input_and_errors(engine, twflow, oracle):

@@ -413,6 +413,23 @@ def test_png_chunk_rules_of_libpng_and_header_bounds(lib, tmp_path):
     assert _load(lib, tmp_path / "o2.png") is None
     (tmp_path / "o3.png").write_bytes(sig + _png_chunk(b"IHDR", pih) + _png_chunk(b"IDAT", zlib.compress(praw)) + _png_chunk(b"PLTE", pal) + _png_chunk(b"IEND", b""))
     assert _load(lib, tmp_path / "o3.png") is None
+    # ADVICE r4 (parity unpinned: no fixture of the reference is such a file; the rules are libpng 1.5's png_check_IHDR /
+    # png_handle_unknown / png_read_end, which cv::imread runs inside its setjmp block): IHDR of another length, a
+    # non-zero compression or filter method, an unknown CRITICAL chunk, a bad IEND CRC, no IEND at all
+    idat, iend = _png_chunk(b"IDAT", z), _png_chunk(b"IEND", b"")
+    bad = {
+        "ihdr14": sig + _png_chunk(b"IHDR", ihdr + b"\0") + idat + iend,
+        "comp1": sig + _png_chunk(b"IHDR", ihdr[:10] + b"\1" + ihdr[11:]) + idat + iend,
+        "filt1": sig + _png_chunk(b"IHDR", ihdr[:11] + b"\1" + ihdr[12:]) + idat + iend,
+        "critical": sig + _png_chunk(b"IHDR", ihdr) + _png_chunk(b"ABcD", b"xyz") + idat + iend,
+        "iendcrc": flip_crc(sig + _png_chunk(b"IHDR", ihdr) + idat + iend, b"IEND"),
+        "noiend": sig + _png_chunk(b"IHDR", ihdr) + idat,
+    }
+    for name, blob in bad.items():
+        (tmp_path / (name + ".png")).write_bytes(blob)
+        assert _load(lib, tmp_path / (name + ".png")) is None, name
+    (tmp_path / "anc.png").write_bytes(sig + _png_chunk(b"IHDR", ihdr) + _png_chunk(b"abCd", b"xyz") + idat + iend)
+    assert np.array_equal(_load(lib, tmp_path / "anc.png"), g)  # an unknown ANCILLARY chunk is skipped
     # huge header, tiny body: refused without allocating the announced image (RLIMIT_AS would make a 1-8 GiB
     # allocation fail loudly; the decoders must not even try) and without reporting its size
     huge_ihdr = (32768).to_bytes(4, "big") + (32768).to_bytes(4, "big") + bytes([16, 6, 0, 0, 0])

@@ -8,6 +8,7 @@
 #include "twflow_kernels.hip.h"
 
 #include <hip/hip_runtime.h>
+#include <unistd.h>
 
 #include <dlfcn.h>
 #include <float.h>
@@ -25,6 +26,7 @@
 #include <vector>
 
 #include "../../include/twflow.h"
+#include "../../include/twflow_debug.h"
 
 using namespace twk;
 
@@ -427,6 +429,64 @@ namespace {
 
 size_t staged_image_bytes(int w, int h);
 
+// ---- the runtime is never handed a pageable host pointer ------------------------------------------------
+// Round 4 recorded a GPU memory-access fault on a malloc-heap address inside a synchronous copy, right after a
+// hipHostRegister / hipHostUnregister cycle on a neighbouring, non-page-aligned heap block: for a
+// pageable operand the runtime pins the enclosing pages on the fly, and that pinning raced with the pages a partial-page
+// registration had just released.  Two rules close it at the source: tw_host_register only takes whole pages the
+// caller owns (below), and EVERY synchronous copy of this library whose host side is not a page-locked range the
+// library knows goes through the engine's own page-locked bounce buffer, in bounded chunks.
+bool host_range_is_page_locked(const void* p, size_t n);  // PinRegistry::covers (defined below)
+constexpr size_t BOUNCE_CHUNK = 8u << 20;
+tw_status bounce_reserve(tw_engine* e, size_t bytes)
+{
+    if (bytes <= e->h_bounce_cap) return TW_OK;
+    if (e->h_bounce) (void)hipHostFree(e->h_bounce);
+    e->h_bounce = nullptr;
+    e->h_bounce_cap = 0;
+    TW_HIP(e, hipHostMalloc((void**)&e->h_bounce, bytes, hipHostMallocDefault));
+    e->h_bounce_cap = bytes;
+    return TW_OK;
+}
+// synchronous host -> device / device -> host copies of any host pointer (null stream, like the hipMemcpy they replace)
+tw_status h2d_sync(tw_engine* e, void* d, const void* h, size_t n)
+{
+    if (!n) return TW_OK;
+    if (host_range_is_page_locked(h, n)) {
+        TW_HIP(e, hipMemcpy(d, h, n, hipMemcpyHostToDevice));
+        return TW_OK;
+    }
+    tw_status r = bounce_reserve(e, std::min(n, BOUNCE_CHUNK));
+    if (r) return r;
+    for (size_t o = 0; o < n; o += BOUNCE_CHUNK) {
+        const size_t k = std::min(BOUNCE_CHUNK, n - o);
+        memcpy(e->h_bounce, (const uint8_t*)h + o, k);
+        TW_HIP(e, hipMemcpy((uint8_t*)d + o, e->h_bounce, k, hipMemcpyHostToDevice));
+    }
+    return TW_OK;
+}
+tw_status d2h_sync(tw_engine* e, void* h, const void* d, size_t n)
+{
+    if (!n) return TW_OK;
+    if (host_range_is_page_locked(h, n)) {
+        TW_HIP(e, hipMemcpy(h, d, n, hipMemcpyDeviceToHost));
+        return TW_OK;
+    }
+    tw_status r = bounce_reserve(e, std::min(n, BOUNCE_CHUNK));
+    if (r) return r;
+    for (size_t o = 0; o < n; o += BOUNCE_CHUNK) {
+        const size_t k = std::min(BOUNCE_CHUNK, n - o);
+        TW_HIP(e, hipMemcpy(e->h_bounce, (const uint8_t*)d + o, k, hipMemcpyDeviceToHost));
+        memcpy((uint8_t*)h + o, e->h_bounce, k);
+    }
+    return TW_OK;
+}
+#define TW_TRY(call)                      \
+    do {                                  \
+        const tw_status _st = (call);     \
+        if (_st != TW_OK) return _st;     \
+    } while (0)
+
 // scoped device allocations (per-stage test entry points, slow paths)
 struct Tmp {
     std::vector<void*> v;
@@ -449,7 +509,7 @@ tw_status upload_vec(tw_engine* e, Plan* pl, const std::vector<T>& v, T** out)
     void* d = nullptr;
     TW_HIP(e, hipMalloc(&d, v.size() * sizeof(T) + 16));
     pl->owned.push_back(d);
-    TW_HIP(e, hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    TW_TRY(h2d_sync(e, d, v.data(), v.size() * sizeof(T)));
     *out = (T*)d;
     return TW_OK;
 }
@@ -1435,6 +1495,7 @@ PinRegistry& pin_registry()
     static PinRegistry r;
     return r;
 }
+bool host_range_is_page_locked(const void* p, size_t n) { return pin_registry().covers(p, n); }
 
 size_t png_rows_bytes(int width, int height, int ch) { return (size_t)height * ((size_t)width * (size_t)ch + 1); }
 
@@ -1531,18 +1592,25 @@ tw_status submit_common(tw_engine* e, const uint8_t* h_a, const uint8_t* h_b, co
             if (c->filt_slot == 0) {
                 // first filtered image of this batch: slots as large as the region allows, at least what it needs
                 const size_t have = c->d_filt_cap / (2 * (size_t)e->cap) / 256 * 256;
-                c->filt_slot = std::max(filt_need, have);
-                if (c->filt_slot * 2 * (size_t)e->cap > c->d_filt_cap) {
+                const size_t slot = std::max(filt_need, have);
+                if (slot * 2 * (size_t)e->cap > c->d_filt_cap) {
                     TW_HIP(e, hipStreamSynchronize(e->copy_stream));
                     if (c->d_filt_raw) (void)hipFree(c->d_filt_raw);
                     c->d_filt = c->d_filt_raw = nullptr;
                     c->d_filt_cap = 0;
                     // 256 bytes of slack on either side: tw_png_unfilter fetches whole 16-byte groups and may read a few
                     // bytes before the first and after the last row of an image
-                    TW_HIP(e, hipMalloc((void**)&c->d_filt_raw, c->filt_slot * 2 * (size_t)e->cap + 512));
+                    TW_HIP(e, hipMalloc((void**)&c->d_filt_raw, slot * 2 * (size_t)e->cap + 512));
                     c->d_filt = c->d_filt_raw + 256;
-                    c->d_filt_cap = c->filt_slot * 2 * (size_t)e->cap;
+                    c->d_filt_cap = slot * 2 * (size_t)e->cap;
                 }
+                // (only now — a failed synchronise / allocation above leaves filt_slot at 0, so that the next
+                // filtered image of this batch tries again instead of copying to a null region)
+                c->filt_slot = slot;
+            }
+            if (!c->d_filt) {
+                e->err = "tw_submit_png8: no device region for the filtered rows";
+                return TW_E_NOMEM;
             }
             const uint8_t* src[2] = {h_a, h_b};
             const int chs[2] = {ch_a, ch_b};
@@ -1943,9 +2011,7 @@ tw_status tw_wait(tw_engine* e, tw_ticket ticket, tw_vector* out, int cap, int* 
             // rare: more hits than the eager copy holds; the batch context's own record region still has them
             const size_t G = (size_t)tw_grid_capacity(c->w, c->h, c->span);
             extra.resize(want);
-            TW_HIP(e, hipMemcpy(extra.data(), c->d_rec + (size_t)j * G,
-                                (size_t)want * sizeof(ScanRec),
-                                hipMemcpyDeviceToHost));
+            TW_TRY(d2h_sync(e, extra.data(), c->d_rec + (size_t)j * G, (size_t)want * sizeof(ScanRec)));
             hr = extra.data();
         }
         if (out)
@@ -2040,7 +2106,7 @@ tw_status tw_dev_upload(tw_engine* e, void* dptr, const void* host, size_t bytes
 {
     if (!e || !dptr || !host) return TW_E_BAD_PARAMETER;
     TW_HIP(e, hipSetDevice(e->device));
-    TW_HIP(e, hipMemcpy(dptr, host, bytes, hipMemcpyHostToDevice));
+    TW_TRY(h2d_sync(e, dptr, host, bytes));
     return TW_OK;
 }
 
@@ -2078,6 +2144,18 @@ tw_status tw_host_free(tw_engine* e, void* hptr)
 tw_status tw_host_register(tw_engine* e, void* hptr, size_t bytes)
 {
     if (!e || !hptr || !bytes) return TW_E_BAD_PARAMETER;
+    // Whole pages only, and only pages the caller owns outright: a range that starts or ends inside a page shares
+    // that page with whatever else the allocator placed there, and page-locking / releasing it behind the runtime's
+    // back is what round 4's GPU fault traced to (a pageable copy of a NEIGHBOURING heap block right after such a
+    // block's hipHostUnregister).  malloc / new / cv::Mat heap blocks are refused: take the memory from
+    // tw_host_alloc, or from an allocation of your own that is page-aligned and a page multiple (mmap,
+    // aligned_alloc(page, n * page), posix_memalign).
+    const size_t page = (size_t)sysconf(_SC_PAGESIZE);
+    if (((uintptr_t)hptr % page) != 0 || (bytes % page) != 0) {
+        e->err = "tw_host_register: the range must start on a page boundary and be a whole number of pages (" +
+                 std::to_string(page) + " bytes): register memory you own page-wise (mmap / aligned_alloc) or use tw_host_alloc";
+        return TW_E_BAD_PARAMETER;
+    }
     TW_HIP(e, hipSetDevice(e->device));
     TW_HIP(e, hipHostRegister(hptr, bytes, hipHostRegisterPortable));
     pin_registry().add(hptr, bytes, PinRegistry::REGISTERED);
@@ -2231,16 +2309,6 @@ double tw_min_traffic_bytes_pair(const tw_engine* e, int width, int height, int 
 namespace {
 // (through the engine's page-locked bounce buffer, like tw_flow_u8: the runtime is never handed a pageable pointer for a
 // pitched copy — round 4)
-tw_status bounce_reserve(tw_engine* e, size_t bytes)
-{
-    if (bytes <= e->h_bounce_cap) return TW_OK;
-    if (e->h_bounce) (void)hipHostFree(e->h_bounce);
-    e->h_bounce = nullptr;
-    e->h_bounce_cap = 0;
-    TW_HIP(e, hipHostMalloc((void**)&e->h_bounce, bytes, hipHostMallocDefault));
-    e->h_bounce_cap = bytes;
-    return TW_OK;
-}
 tw_status up_planes(tw_engine* e, float* d, int ld, long long ps, const float* h, int w, int hh, int planes)
 {
     const size_t plane = (size_t)w * hh * 4;
@@ -2271,7 +2339,7 @@ extern "C" int tw_debug_stamps(tw_engine* e, unsigned long long* out)
 {
     if (!e || !e->dbg_stamps || !out) return 0;
     if (hipSetDevice(e->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return 0;
-    return hipMemcpy(out, e->dbg_stamps, 64 * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 256 : 0;
+    return d2h_sync(e, out, e->dbg_stamps, 64 * 4 * sizeof(unsigned long long)) == TW_OK ? 256 : 0;
 }
 
 // number of captured single-pair schedules this engine holds (tests: the graph path is really the one that ran)
@@ -2298,6 +2366,47 @@ extern "C" int tw_debug_occupancy(char* buf, int cap)
     add("tw_update_matrices<true,2>", (const void*)tw_update_matrices<true, 2>, 256, 0);
     add("tw_pyr_k3<0>", (const void*)tw_pyr_k3<0>, 256, 0);
     return n;
+}
+
+// ---- the yardstick: a plain float4 device copy (SURVEY 8d "measured device-copy peak taken in the same run") -----------
+// One 16-byte load and one 16-byte store per lane and iteration, grid-stride, 8 workgroups of 256 per CU: the same
+// shape MI355X_MICROARCH.md quotes its 6.29 TB/s for, so that bench.py's `frac_of_measured_copy` is comparable with it
+// (a torch copy_ measured 12 % lower in round 4).
+__global__ __launch_bounds__(256) void tw_copy_f4(const float4* __restrict__ src, float4* __restrict__ dst, size_t n)
+{
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+}
+extern "C" tw_status tw_debug_copy_rate(tw_engine* e, size_t bytes, int reps, double* gbps)
+{
+    if (!e || !gbps || bytes < 4096 || reps < 1) return TW_E_BAD_PARAMETER;
+    TW_HIP(e, hipSetDevice(e->device));
+    Tmp t;
+    float4* a = (float4*)t.alloc<uint8_t>(bytes);
+    float4* b = (float4*)t.alloc<uint8_t>(bytes);
+    if (!a || !b) return TW_E_NOMEM;
+    hipStream_t st = e->stream;
+    TW_HIP(e, hipMemsetAsync(a, 1, bytes, st));
+    hipDeviceProp_t pr;
+    TW_HIP(e, hipGetDeviceProperties(&pr, e->device));
+    const size_t n = bytes / 16;
+    const int grid = pr.multiProcessorCount * 8;
+    hipEvent_t ea, eb;
+    TW_HIP(e, hipEventCreate(&ea));
+    TW_HIP(e, hipEventCreate(&eb));
+    hipLaunchKernelGGL(tw_copy_f4, dim3(grid), dim3(256), 0, st, a, b, n);  // warm-up
+    (void)hipEventRecord(ea, st);
+    for (int i = 0; i < reps; i++) hipLaunchKernelGGL(tw_copy_f4, dim3(grid), dim3(256), 0, st, a, b, n);
+    (void)hipEventRecord(eb, st);
+    hipError_t err = hipStreamSynchronize(st);
+    float ms = 0.f;
+    if (err == hipSuccess) err = hipEventElapsedTime(&ms, ea, eb);
+    (void)hipEventDestroy(ea);
+    (void)hipEventDestroy(eb);
+    TW_HIP(e, err);
+    TW_HIP(e, hipGetLastError());
+    *gbps = 2.0 * (double)(n * 16) * reps / (ms * 1e-3) / 1e9;  // read + write counted
+    return TW_OK;
 }
 
 // ---- isolated kernel timing on synthetic device data (bench.py, tools/kbench.py) -------------------------
@@ -2344,10 +2453,10 @@ extern "C" tw_status tw_bench_stage(tw_engine* e, int kclass, int width, int hei
             hm[4 * ps + i] = 2.0f * cosf((float)(i % 2477) * 0.003f);
         }
         for (int j = 0; j < npairs; j++) {
-            TW_HIP(e, hipMemcpy(R + ps * 10 * j, hb.data(), ps * 10 * 4, hipMemcpyHostToDevice));
-            TW_HIP(e, hipMemcpy(M0 + ps * 5 * j, hm.data(), ps * 5 * 4, hipMemcpyHostToDevice));
-            TW_HIP(e, hipMemcpy(M1 + ps * 5 * j, hm.data(), ps * 5 * 4, hipMemcpyHostToDevice));
-            TW_HIP(e, hipMemcpy(I + ps * 2 * j, hb.data() + 17, ps * 2 * 4, hipMemcpyHostToDevice));
+            TW_TRY(h2d_sync(e, R + ps * 10 * j, hb.data(), ps * 10 * 4));
+            TW_TRY(h2d_sync(e, M0 + ps * 5 * j, hm.data(), ps * 5 * 4));
+            TW_TRY(h2d_sync(e, M1 + ps * 5 * j, hm.data(), ps * 5 * 4));
+            TW_TRY(h2d_sync(e, I + ps * 2 * j, hb.data() + 17, ps * 2 * 4));
         }
         std::vector<float> hf(std::max(ps, pps) * 2);
         for (size_t i = 0; i < hf.size(); i++) hf[i] = 3.f * sinf((float)(i % 977) * 0.01f) + (flags & 1 ? rnd() * 8.f : 0.f);
@@ -2355,14 +2464,14 @@ extern "C" tw_status tw_bench_stage(tw_engine* e, int kclass, int width, int hei
         for (uint8_t& v : hi) v = (uint8_t)((rnd() + 0.5f) * 255.f);
         std::vector<const uint8_t*> ht(2 * (size_t)npairs);
         for (int j = 0; j < npairs; j++) {
-            TW_HIP(e, hipMemcpy(fl + ps * 2 * j, hf.data(), ps * 2 * 4, hipMemcpyHostToDevice));
-            TW_HIP(e, hipMemcpy(pf + pps * 2 * j, hf.data(), pps * 2 * 4, hipMemcpyHostToDevice));
+            TW_TRY(h2d_sync(e, fl + ps * 2 * j, hf.data(), ps * 2 * 4));
+            TW_TRY(h2d_sync(e, pf + pps * 2 * j, hf.data(), pps * 2 * 4));
             for (int q = 0; q < 2; q++) {
-                TW_HIP(e, hipMemcpy(img + npx0 * (2 * j + q), hi.data(), npx0, hipMemcpyHostToDevice));
+                TW_TRY(h2d_sync(e, img + npx0 * (2 * j + q), hi.data(), npx0));
                 ht[2 * j + q] = img + npx0 * (2 * j + q);
             }
         }
-        TW_HIP(e, hipMemcpy((void*)tab, ht.data(), sizeof(void*) * ht.size(), hipMemcpyHostToDevice));
+        TW_TRY(h2d_sync(e, (void*)tab, ht.data(), sizeof(void*) * ht.size()));
     }
     hipStream_t st = e->stream;
     hipEvent_t ea, eb;
@@ -2429,9 +2538,9 @@ tw_status tw_stage_pyr_level(tw_engine* e, const uint8_t* img, int w0, int h0, i
     float* d_I = t.alloc<float>((size_t)L.ps);
     const uint8_t** d_tab = t.alloc<const uint8_t*>(1);
     if (!d_img || !d_I || !d_tab) return TW_E_NOMEM;
-    TW_HIP(e, hipMemcpy(d_img, img, (size_t)w0 * h0, hipMemcpyHostToDevice));
+    TW_TRY(h2d_sync(e, d_img, img, (size_t)w0 * h0));
     const uint8_t* hp = d_img;
-    TW_HIP(e, hipMemcpy((void*)d_tab, &hp, sizeof(hp), hipMemcpyHostToDevice));
+    TW_TRY(h2d_sync(e, (void*)d_tab, &hp, sizeof(hp)));
     hipStream_t st = e->stream;
     e->img_aligned4 = 1;  // hipMalloc'ed image, dense rows: the kernel itself checks stride % 4
     launch_pyr(e, st, pl, level, d_tab, w0, d_I, 1);
@@ -2463,13 +2572,13 @@ tw_status tw_stage_png_unfilter(tw_engine* e, const uint8_t* rows, int channels,
     uint8_t* d_gray = t.alloc<uint8_t>(staged_image_bytes(w, h));
     PngJob* d_job = t.alloc<PngJob>(1);
     if (!d_rows || !d_gray || !d_job) return TW_E_NOMEM;
-    TW_HIP(e, hipMemcpy(d_rows, rows, nb, hipMemcpyHostToDevice));
+    TW_TRY(h2d_sync(e, d_rows, rows, nb));
     PngJob pj;
     pj.src = d_rows;
     pj.dst = d_gray;
     pj.ch = channels;
     pj.pad = 0;
-    TW_HIP(e, hipMemcpy(d_job, &pj, sizeof(pj), hipMemcpyHostToDevice));
+    TW_TRY(h2d_sync(e, d_job, &pj, sizeof(pj)));
     PngArgs pa;
     pa.jobs = d_job;
     pa.w = w;
@@ -2480,7 +2589,7 @@ tw_status tw_stage_png_unfilter(tw_engine* e, const uint8_t* rows, int channels,
     else hipLaunchKernelGGL(tw_png_unfilter<1>, dim3(1), dim3(64), 0, st, pa);
     TW_HIP(e, hipGetLastError());
     TW_HIP(e, hipStreamSynchronize(st));
-    TW_HIP(e, hipMemcpy(gray, d_gray, (size_t)w * h, hipMemcpyDeviceToHost));
+    TW_TRY(d2h_sync(e, gray, d_gray, (size_t)w * h));
     return TW_OK;
 }
 
@@ -2555,10 +2664,10 @@ tw_status tw_stage_flow_upsample_update(tw_engine* e, const float* R0_5, const f
     if ((r = up_planes(e, d_R, ld, ps, R0_5, w, h, 5)) || (r = up_planes(e, d_R + 5 * ps, ld, ps, R1_5, w, h, 5)) ||
         (r = up_planes(e, d_p, pld, pps, prevflow2, pw, ph, 2)))
         return r;
-    TW_HIP(e, hipMemcpy(d_xo, u.xofs.data(), (size_t)w * 4, hipMemcpyHostToDevice));
-    TW_HIP(e, hipMemcpy(d_yo, u.yofs.data(), (size_t)h * 4, hipMemcpyHostToDevice));
-    TW_HIP(e, hipMemcpy(d_al, u.alpha.data(), (size_t)w * 8, hipMemcpyHostToDevice));
-    TW_HIP(e, hipMemcpy(d_be, u.beta.data(), (size_t)h * 8, hipMemcpyHostToDevice));
+    TW_TRY(h2d_sync(e, d_xo, u.xofs.data(), (size_t)w * 4));
+    TW_TRY(h2d_sync(e, d_yo, u.yofs.data(), (size_t)h * 4));
+    TW_TRY(h2d_sync(e, d_al, u.alpha.data(), (size_t)w * 8));
+    TW_TRY(h2d_sync(e, d_be, u.beta.data(), (size_t)h * 8));
     UpdArgs a;
     memset(&a, 0, sizeof(a));
     a.R = d_R;

@@ -348,24 +348,28 @@ static bool png_parse(const std::vector<uint8_t>& d, PngStream& ps)
     int depth = 0, ctype = 0, interlace = 0;
     std::vector<uint8_t>& idat = ps.idat;
     std::vector<uint8_t>& plte = ps.plte;
-    bool have_ihdr = false, idat_done = false, first = true;
+    bool have_ihdr = false, idat_done = false, first = true, have_iend = false;
     // Chunk rules the way libpng (cv::imread) enforces them — a file it refuses answers "Can't open" here as well
     // (ADVICE r3): IHDR first; the CRC of every CRITICAL chunk (IHDR, PLTE, IDAT; an upper-case first letter) must
     // hold — a mismatch there is png_error, in an ancillary chunk only a warning; IDAT chunks are consecutive; PLTE
-    // comes before IDAT.
+    // comes before IDAT.  ADVICE r4 (parity unpinned — no fixture of the reference is such a file): IHDR is exactly 13
+    // bytes with compression method 0 and filter method 0 (png_check_IHDR); a critical chunk libpng does not know is
+    // png_chunk_error; IEND is a critical chunk too (its CRC must hold) and must be there — cv::imread calls
+    // png_read_end inside its setjmp block, so a file that stops after its last IDAT fails to open.
     while (p + 12 <= d.size()) {
         const uint32_t len = be32(&d[p]);
         const char* type = (const char*)&d[p + 4];
         if (p + 12 + (size_t)len > d.size()) return false;
         const uint8_t* data = &d[p + 8];
         const bool critical = !(type[0] & 0x20);
-        if (critical && memcmp(type, "IEND", 4) != 0 && png_crc32(&d[p + 4], 4 + (size_t)len) != be32(data + len)) return false;
+        if (critical && png_crc32(&d[p + 4], 4 + (size_t)len) != be32(data + len)) return false;
         if (first && memcmp(type, "IHDR", 4) != 0) return false;
         first = false;
         const bool is_idat = !memcmp(type, "IDAT", 4);
         if (!is_idat && !idat.empty()) idat_done = true;
         if (!memcmp(type, "IHDR", 4)) {
-            if (len < 13 || have_ihdr) return false;
+            if (len != 13 || have_ihdr) return false;
+            if (data[10] != 0 || data[11] != 0) return false;  // compression method, filter method
             w = (int)be32(data);
             h = (int)be32(data + 4);
             depth = data[8];
@@ -379,10 +383,14 @@ static bool png_parse(const std::vector<uint8_t>& d, PngStream& ps)
             if (idat_done) return false;  // IDATs must be consecutive
             idat.insert(idat.end(), data, data + len);
         } else if (!memcmp(type, "IEND", 4)) {
+            have_iend = true;
             break;
+        } else if (critical) {
+            return false;  // unknown critical chunk
         }
         p += 12 + (size_t)len;
     }
+    if (!have_iend) return false;
     if (!have_ihdr || w < 1 || h < 1 || w > 32768 || h > 32768 || interlace > 1) return false;
     int ch;
     switch (ctype) {
@@ -933,15 +941,25 @@ void Consumer::run()
             constexpr size_t kArenaMax = (size_t)4 << 30;       // per arena, three arenas per consumer
             Arena& ar = arena[arena_idx];  // (its last user was the batch three back: collected below before this one)
             arena_idx = (arena_idx + 1) % 3;
+            // the arena is sized from PNG HEADERS, before anything is inflated.  Up to a 4K RGBA screenshot per
+            // slot (kArenaFullBatchSlot) it is sized for a full batch at once (no regrowth while a batch fills up); a
+            // larger slot gets only what the jobs actually present need, and an arena that an unusual batch blew up is
+            // given back as soon as a batch needs less than a quarter of it — one 8192 x 8192 header pair no longer pins
+            // 3 x 4 GiB per consumer for the life of the process (worst cases: INTEGRATION.md).
+            constexpr size_t kArenaFullBatchSlot = (size_t)40 << 20;
+            constexpr size_t kArenaShrinkAbove = (size_t)1 << 30;
             auto ensure_arena = [&](size_t slot) {
                 const size_t need = std::min(kArenaMax, slot * 2 * jobs.size());
-                if (!eng || !slot || need <= ar.cap) return;
+                if (!eng || !slot) return;
+                const bool oversized = ar.base && ar.cap > kArenaShrinkAbove && need <= ar.cap / 4;
+                if (need <= ar.cap && !oversized) return;
                 if (ar.base) (void)tw_host_free(eng, ar.base);
                 ar.base = nullptr;
                 ar.cap = 0;
                 void* hp = nullptr;
-                // a full batch of this size (no regrowth), within the bound
-                const size_t want = std::min(kArenaMax, std::max(need, slot * 2 * (size_t)batch_));
+                // a full batch of this size (no regrowth), within the bound — for ordinary slots only
+                const size_t full = slot <= kArenaFullBatchSlot ? slot * 2 * (size_t)batch_ : need;
+                const size_t want = std::min(kArenaMax, std::max(need, full));
                 if (tw_host_alloc(eng, want, &hp) == TW_OK) {
                     ar.base = (uint8_t*)hp;
                     ar.cap = want;

@@ -43,7 +43,7 @@ class TwError(RuntimeError):
 
 _lib = None
 
-# every symbol include/twflow.h declares
+# every symbol include/twflow.h and include/twflow_debug.h (diagnostics, not part of the boundary) declare
 OPT_SCAN_FUSED_FINAL = 1
 OPT_POLYEXP_F32 = 2
 
@@ -54,6 +54,7 @@ SYMBOLS = [
     "tw_prof_select", "tw_prof_read",
     "tw_algorithmic_bytes", "tw_algorithmic_bytes_pair", "tw_min_traffic_bytes_pair", "tw_num_levels", "tw_level_chunk", "tw_bench_stage", "tw_stage_pyr_level",
     "tw_stage_png_unfilter", "tw_stage_polyexp", "tw_stage_update_matrices", "tw_stage_flow_upsample_update", "tw_stage_blur_solve",
+    "tw_debug_graphs", "tw_debug_occupancy", "tw_debug_stamps", "tw_debug_copy_rate",
 ]
 
 
@@ -148,6 +149,7 @@ def _bind(path):
     L.tw_stage_flow_upsample_update.argtypes = [vp, fp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, fp, fp]
     L.tw_stage_blur_solve.argtypes = [vp, fp, fp, fp, C.c_int, C.c_int, C.c_int, fp, fp]
     L.tw_has_variants.restype = C.c_int
+    L.tw_debug_copy_rate.argtypes = [vp, C.c_size_t, C.c_int, C.POINTER(C.c_double)]
     L.tw_debug_graphs.argtypes = [vp]
     L.tw_debug_graphs.restype = C.c_int
     return L
@@ -353,6 +355,12 @@ class Engine:
     # ---- instrumentation -------------------------------------------------------------------------------
     def prof_select(self, kclass, level=-1):
         self._check(self._L.tw_prof_select(self._h, kclass, level))
+
+    def copy_rate_gbps(self, nbytes=1 << 30, reps=10):
+        """The yardstick: GB/s (read + write) of a float4 device copy kernel on this engine's stream (twflow_debug.h)."""
+        g = C.c_double()
+        self._check(self._L.tw_debug_copy_rate(self._h, nbytes, reps, C.byref(g)))
+        return g.value
 
     def prof_read(self, kclass):
         ms = C.c_double()
