@@ -818,6 +818,7 @@ void Consumer::run()
             int n = 0;
             float sec = 0;
             tw_status r = tw_wait(eng, s.ticket, v, cap, &n, &sec);
+            if (shared_) shared_->inflight--;
             if (r != TW_OK) {
                 s.err = std::string(tw_last_error(eng)[0] ? tw_last_error(eng) : tw_strerror(r));
             } else {
@@ -842,6 +843,7 @@ void Consumer::run()
         mine.pairs++;
         mine.lastResponseNs = steady_ns();
         publish();  // before the response leaves: whoever has seen N responses sees N pairs in the stats
+        res.pushedNs = mine.lastResponseNs;
         res_.push(std::move(res));
     };
     // Two batches are kept going: the one just submitted computes while the next one is popped, decoded and
@@ -861,7 +863,26 @@ void Consumer::run()
         for (Staged& s : v) finish(s);
         v.clear();
     };
+    // Fair share (round 5; the N = 8 ceiling run on the stub backend, tests/test_host_queue.py): a consumer keeps up to
+    // three batches going, so near the END of a run — or for a run as short as BASELINE config 4's 2 048 pairs on 8 GPUs —
+    // three consumers used to hold nine full batches while five idled (21.6 k instead of 32.7 k pairs/s).  What is left
+    // (queued + in flight everywhere) is shared evenly: a consumer that already holds its share delivers its oldest batch
+    // before it takes more, and never takes more than what brings it up to the share.
+    auto own_inflight = [&] {
+        long k = 0;
+        for (const Staged& s : prev) k += s.submitted && !s.done;
+        for (const Staged& s : prev2) k += s.submitted && !s.done;
+        return k;
+    };
+    auto fair_share = [&] {
+        const long total = (long)req_.size() + (shared_ ? shared_->inflight.load() : own_inflight());
+        return (total + (long)n_consumers_ - 1) / (long)n_consumers_;
+    };
     for (;;) {
+        for (long own = own_inflight(); own > 0 && own >= fair_share() + (long)batch_ / 8; own = own_inflight()) {
+            if (!prev2.empty()) finish_all(prev2);
+            else finish_all(prev);
+        }
         Request first;
         if (!req_.tryPopNow(first)) {
             finish_all(prev2);  // nothing queued: deliver what is outstanding before blocking
@@ -888,8 +909,10 @@ void Consumer::run()
         jobs[0].req = std::move(first);
         // a consumer takes at most its share of what is queued, so that a short queue is spread over all GPUs
         // (a greedy grab of `batch` jobs starves the other consumers)
+        // (its share of the queue alone, and — above — of everything that is left including what the engines still hold)
         const size_t share = (req_.size() + 1 + (size_t)n_consumers_ - 1) / (size_t)n_consumers_;
-        const size_t take = std::max<size_t>(1, std::min<size_t>((size_t)batch_, share));
+        const long room = fair_share() + 1 - own_inflight();
+        const size_t take = std::max<size_t>(1, std::min<size_t>({(size_t)batch_, share, (size_t)std::max(1L, room)}));
         Request more;
         while (jobs.size() < take && req_.tryPopNow(more)) {
             jobs.emplace_back();
@@ -1075,8 +1098,10 @@ void Consumer::run()
                 for (size_t q = 0; q < k; q++) finish(jobs[q]);
                 r = submit();
             }
-            if (r == TW_OK) s.submitted = true;
-            else s.err = std::string(tw_last_error(eng)[0] ? tw_last_error(eng) : tw_strerror(r));
+            if (r == TW_OK) {
+                s.submitted = true;
+                if (shared_) shared_->inflight++;
+            } else s.err = std::string(tw_last_error(eng)[0] ? tw_last_error(eng) : tw_strerror(r));
         }
         if (eng) (void)tw_flush(eng);  // a partly filled batch starts now, not when its first result is asked for
         bt3 = steady_ns();
@@ -1155,7 +1180,21 @@ std::vector<ConsumerStats> Manager::consumerStats()
     return shared_.stats;
 }
 
-void Manager::markEpoch() { shared_.epoch++; }
+void Manager::markEpoch()
+{
+    shared_.epoch++;
+    std::lock_guard<std::mutex> lk(report_m_);
+    pump_stats_ = PumpStats();
+    pump_sum_us_ = 0;
+}
+
+PumpStats Manager::pumpStats()
+{
+    std::lock_guard<std::mutex> lk(report_m_);
+    PumpStats p = pump_stats_;
+    p.meanUs = p.delivered ? pump_sum_us_ / (double)p.delivered : 0;
+    return p;
+}
 
 int Manager::request(const std::string& expect_image, const std::string& target_image)
 {
@@ -1201,19 +1240,27 @@ void Manager::work()
 {
     Response res;
     while (responseQueue_.tryPop(res)) {  // src/manager.cpp:80-90 + notify() :102-116
-        if (res.status == "ERROR") {
-            {
-                std::lock_guard<std::mutex> lk(report_m_);
-                report_.errorCount++;
+        const long long t_pop = steady_ns();
+        const bool is_err = res.status == "ERROR";
+        {
+            std::lock_guard<std::mutex> lk(report_m_);
+            if (is_err) report_.errorCount++;
+            else report_.dataCount++;
+            if (res.pushedNs) {
+                const double us = (double)(t_pop - res.pushedNs) * 1e-3;
+                pump_stats_.delivered++;
+                pump_sum_us_ += us;
+                if (us > pump_stats_.maxUs) pump_stats_.maxUs = us;
             }
+        }
+        if (is_err) {
             if (obs_.onError) obs_.onError(res.reason);
         } else {
-            {
-                std::lock_guard<std::mutex> lk(report_m_);
-                report_.dataCount++;
-            }
             if (obs_.onNext) obs_.onNext(res);
         }
+        const double cb_ms = (double)(steady_ns() - t_pop) * 1e-6;
+        std::lock_guard<std::mutex> lk(report_m_);
+        pump_stats_.busyMs += cb_ms;
     }
     requestQueue_.stop();  // src/manager.cpp:93-97
     for (Consumer* c : consumers_) c->join();

@@ -45,6 +45,14 @@ struct Response {
     int span = 0;
     std::string status, reason;
     int width = 0, height = 0;
+    long long pushedNs = 0;  // host-internal: when the consumer handed the response to the pump (steady clock)
+};
+// How long responses sat between a consumer's push and the observer's callback since the last markEpoch() — the one
+// pump thread of src/manager.cpp:80-90 is where N consumers' results are serialised
+struct PumpStats {
+    long delivered = 0;
+    double meanUs = 0, maxUs = 0;
+    double busyMs = 0;  // time the pump spent inside the observer's callbacks
 };
 struct Report {
     int requestCount = 0, dataCount = 0, errorCount = 0;
@@ -176,6 +184,7 @@ struct ConsumerShared {
     std::condition_variable cv;
     std::vector<ConsumerStats> stats;  // [consumer id]
     std::atomic<int> epoch{0};
+    std::atomic<long> inflight{0};  // pairs submitted to an engine and not yet collected, over all consumers
     bool profile = false;
 };
 
@@ -218,6 +227,7 @@ public:
     // every consumer zeroes its counters (and discards its pending kernel events) before the next job it takes;
     // call while the queue is empty and every response has arrived
     void markEpoch();
+    PumpStats pumpStats();
     void stop();  // idempotent; completion is reported through onCompleted
     bool running() const { return running_; }
 
@@ -234,6 +244,8 @@ private:
     Report report_;
     std::mutex report_m_;
     ConsumerShared shared_;
+    PumpStats pump_stats_;
+    double pump_sum_us_ = 0;
 };
 
 }  // namespace twhost

@@ -34,6 +34,7 @@ struct Args {
     int pairs = 2048, devices = 0, per_device = 1, batch = 128, warmup_batches = 2, pinned = 1, files = 0, span = 10;
     int prof = 1;  // event-bracket the level-0 blur / polyexp launches of every consumer's engine
     double threshold = 5.0;
+    int syn_w = 0, syn_h = 0, syn_n = 4;  // --synthetic WxH [--synthetic-pairs N]: random pairs made in memory, no files
 };
 
 bool parse(int argc, char** argv, Args& a)
@@ -55,12 +56,15 @@ bool parse(int argc, char** argv, Args& a)
         else if ((v = val("--span"))) a.span = atoi(v);
         else if ((v = val("--prof"))) a.prof = atoi(v);
         else if ((v = val("--threshold"))) a.threshold = atof(v);
+        else if ((v = val("--synthetic"))) {
+            if (sscanf(v, "%dx%d", &a.syn_w, &a.syn_h) != 2 || a.syn_w < 1 || a.syn_h < 1) return false;
+        } else if ((v = val("--synthetic-pairs"))) a.syn_n = atoi(v);
         else {
             fprintf(stderr, "unknown argument %s\n", argv[i]);
             return false;
         }
     }
-    return !a.dir.empty() && a.pairs > 0 && a.batch > 0;
+    return (!a.dir.empty() || a.syn_w > 0) && a.pairs > 0 && a.batch > 0 && a.syn_n > 0;
 }
 
 struct Img {
@@ -100,7 +104,41 @@ int main(int argc, char** argv)
     }
     std::vector<Img> imgs;
     std::vector<std::string> names;
-    for (int i = 0;; i++) {
+    if (a.syn_w > 0) {
+        // in-memory pairs without a directory (the host-layer ceiling runs on the stub backend): `syn_n` distinct pairs of
+        // LCG noise, every second pair identical (the stub answers one vector when pixel 0 differs)
+        unsigned sd = 12345u;
+        for (int i = 0; i < 2 * a.syn_n; i++) {
+            Img im;
+            im.w = a.syn_w;
+            im.h = a.syn_h;
+            const size_t n = (size_t)im.w * im.h;
+            void* hp = nullptr;
+            if (alloc_eng) {
+                if (tw_host_alloc(alloc_eng, n, &hp) != TW_OK) {
+                    fprintf(stderr, "tw_host_alloc failed\n");
+                    return 3;
+                }
+                im.data = (uint8_t*)hp;
+            } else {
+                im.pageable.resize(n);
+                im.data = im.pageable.data();
+            }
+            if ((i & 1) && ((i >> 1) & 1)) {
+                memcpy(im.data, imgs[(size_t)i - 1].data, n);
+            } else {
+                for (size_t k = 0; k < n; k++) {
+                    sd = sd * 1664525u + 1013904223u;
+                    im.data[k] = (uint8_t)(sd >> 24);
+                }
+            }
+            imgs.push_back(std::move(im));
+            char nm[64];
+            snprintf(nm, sizeof(nm), "synthetic_%d_%c", i >> 1, (i & 1) ? 'b' : 'a');
+            names.push_back(nm);
+        }
+    }
+    for (int i = 0; a.syn_w == 0; i++) {
         bool ok = true;
         for (int q = 0; q < 2 && ok; q++) {
             char path[4096];
@@ -237,6 +275,7 @@ int main(int argc, char** argv)
         cv.wait(lk, [&] { return completed; });
     }
     const std::vector<ConsumerStats> stats = mg->consumerStats();  // the consumers have joined: final numbers
+    const PumpStats pump = mg->pumpStats();
     delete mg;
     if (alloc_eng) {
         for (Img& im : imgs) tw_host_free(alloc_eng, im.data);
@@ -246,11 +285,13 @@ int main(int argc, char** argv)
            "\"engine_batch\": %d, \"distinct_pairs\": %d, \"width\": %d, \"height\": %d, \"input\": \"%s\", "
            "\"errors\": %ld, \"flagged_vectors\": %ld, \"report\": {\"request\": %d, \"data\": %d, \"error\": %d}, "
            "\"first_error\": \"%s\", \"warmup_pairs\": %ld, \"warmup_rounds\": %d, \"all_consumers_warm\": %s, "
+           "\"pump\": {\"delivered\": %ld, \"latency_mean_us\": %.2f, \"latency_max_us\": %.2f, \"callback_busy_ms\": %.3f}, "
            "\"per_consumer\": [",
            a.pairs, sec, a.pairs / sec, ndev, consumers, a.batch, distinct, imgs[0].w, imgs[0].h,
            a.files ? "pgm files" : (a.pinned ? "page-locked host buffers" : "pageable host buffers"), errors,
            flagged - flagged_warm, final_report.requestCount, final_report.dataCount, final_report.errorCount,
-           first_error.c_str(), warm, rounds, all_warm ? "true" : "false");
+           first_error.c_str(), warm, rounds, all_warm ? "true" : "false", pump.delivered, pump.meanUs, pump.maxUs,
+           pump.busyMs);
     for (size_t i = 0; i < stats.size(); i++) {
         const ConsumerStats& cs = stats[i];
         // idle = the part of the timed region this consumer did not work in: before its first job, after its last
