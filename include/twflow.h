@@ -223,6 +223,10 @@ tw_status tw_bench_stage(tw_engine* e, int kclass, int width, int height, int le
  * Layouts: images/planes are dense row-major; R and M are 5 planes [5][h][w]; flow is 2 planes. */
 tw_status tw_stage_pyr_level(tw_engine* e, const uint8_t* img, int w0, int h0, int level, float* I, int* w,
                              int* h);
+/* Levels 3 and 2 of one image from the batch path's one-read kernel (tw_pyr_23; round 5): I3 (w0/8 x h0/8) and I2
+ * (w0/4 x h0/4).  TW_E_UNSUPPORTED when the size has no exact reductions by 4 and 8 (the engine then runs
+ * tw_stage_pyr_level's kernels for those levels). */
+tw_status tw_stage_pyr_fused23(tw_engine* e, const uint8_t* img, int w0, int h0, float* I3, float* I2);
 /* PNG scanline reconstruction + gray conversion of one image (tw_submit_png8's kernel): `rows` = h rows of
  * 1 + w * channels bytes, channels 1-4; `waves` = 0 (the engine's choice for this width), 1, 4 or 16 waves per image. */
 tw_status tw_stage_png_unfilter(tw_engine* e, const uint8_t* rows, int channels, int w, int h, int waves,

@@ -61,6 +61,50 @@ def test_stage_pyr_level_1080p_area_fast_and_large_kernels(engine, oracle):
         assert_same(engine.stage_pyr_level(img, k), oracle.pyr_level(img, plan[k]), "1080p pyr level %d" % k)
 
 
+@pytest.mark.parametrize("h,w", [(1080, 1920), (480, 640), (256, 256), (264, 496), (488, 648), (2160, 3840), (272, 1000)])
+def test_stage_pyr_fused_levels_2_and_3(engine, oracle, twflow, h, w):
+    """Round 5: levels 3 and 2 of an exact pyr_scale = 0.5 pyramid from ONE read of the image
+    (tw_pyr_23, the batch path's kernel) — bit-exact against the oracle's per-level GaussianBlur(19 / 9 taps, REFLECT101)
+    + INTER_LINEAR resize, on full tiles, ragged right / bottom tiles, the smallest eligible size and 4K; sizes whose
+    levels are not exact reductions are refused (the engine keeps tw_pyr_taps for them)."""
+    rng = np.random.default_rng(h * 5 + w)
+    img = rand_img(rng, h, w, smooth=False)
+    img[: h // 5, : w // 7] = 255  # saturated block against the borders
+    plan = oracle.level_plan(w, h)
+    assert len(plan) >= 4
+    I3, I2 = engine.stage_pyr_fused23(img)
+    assert_same(I3, oracle.pyr_level(img, plan[3]), "fused pyramid level 3 of %dx%d" % (w, h))
+    assert_same(I2, oracle.pyr_level(img, plan[2]), "fused pyramid level 2 of %dx%d" % (w, h))
+    assert_same(engine.stage_pyr_level(img, 3), I3, "tw_pyr_taps level 3 == fused")
+
+
+def test_pyr_fused_refused_for_inexact_sizes_and_batches_agree(twflow, oracle):
+    """1366 x 768 has no exact reduction by 8 in x: the stage entry answers TW_E_UNSUPPORTED.  A batch of three 640x480
+    pairs runs tw_pyr_23 (the single-pair schedule does not) and must equal the oracle, and the TW_PYR_FUSED=0 engine."""
+    import os
+    import synth
+    rng = np.random.default_rng(9)
+    with twflow.Engine(0, twflow.default_params(), slots=4) as e:
+        with pytest.raises(twflow.TwError) as ei:
+            e.stage_pyr_fused23(rand_img(rng, 768, 1366))
+        assert ei.value.code == twflow.TW_E_UNSUPPORTED
+        pairs = [synth.make_pair(i, 480, 640) for i in range(3)]
+        want = []
+        for a, b in pairs:
+            wx, wy = oracle.farneback(a, b)
+            want.append(oracle.span_scan(wx, wy, 10, 1.0))
+        tk = [e.submit(a, b, 10, 1.0) for a, b in pairs]
+        got = [e.wait(t)["vector"] for t in tk]
+        assert got == want
+    os.environ["TW_PYR_FUSED"] = "0"
+    try:
+        with twflow.Engine(0, twflow.default_params(), slots=4) as e:
+            tk = [e.submit(a, b, 10, 1.0) for a, b in pairs]
+            assert [e.wait(t)["vector"] for t in tk] == want
+    finally:
+        del os.environ["TW_PYR_FUSED"]
+
+
 @pytest.mark.parametrize("h,w", SIZES + [(540, 960)])
 def test_stage_polyexp(engine, oracle, h, w):
     rng = np.random.default_rng(h * 7 + w)

@@ -236,6 +236,10 @@ struct LevelPlan {
 
 struct Plan {
     int w0 = 0, h0 = 0;
+    // levels 2 and 3 come from ONE launch of tw_pyr_23 (exact halving pyramid, 9- / 19-tap smoothing): set by get_plan
+    // when the resize tables say so; k19 / k9 = [0, taps..., 0...] as the kernel's shared byte windows want them
+    bool fused23 = false;
+    float k19[24] = {0}, k9[16] = {0};
     int levels = 0;  // index of the coarsest level
     std::vector<LevelPlan> lv;
     std::vector<void*> owned;  // device allocations
@@ -377,6 +381,7 @@ struct tw_engine {
     int upd_ny = 2;        // TW_UPD_NY: pixels per lane of tw_update_matrices (1 or 2)
     int scan_fused = 0;    // TW_OPT_SCAN_FUSED_FINAL
     int poly_f32 = 0;      // TW_OPT_POLYEXP_F32 (measurement variant: float accumulators, not bit-exact)
+    int pyr_fused = 1;     // TW_PYR_FUSED=0: levels 2 and 3 as two tw_pyr_taps launches again (A/B; tw_pyr_23 is the default)
     int pyr_generic = 0;   // TW_PYR_GENERIC=1: always the generic pyramid kernel, 2: tw_pyr_level_lds for every level (A/B)
     int blur_variant = 4;  // 4: tw_blur_solve4 (default); 8: tw_blur_solve8 (packed f32) — TW_BLUR_VARIANT
     int pp_waves = 512;    // TW_PP_WAVES: below this many waves of 96x8 tiles a level takes the plane-parallel kernel
@@ -686,6 +691,28 @@ tw_status get_plan(tw_engine* e, int w0, int h0, Plan** out)
             }
         }
     }
+    // tw_pyr_23 eligibility: both levels are exact INTER_LINEAR reductions by 4 and 8 (sample columns s*x + s/2 - 1 and
+    // + 1 with weights 0.5 / 0.5, no single-tap tail, rows alike) with the 9- / 19-tap kernels of pyr_scale = 0.5
+    if (pl->levels >= 3 && pl->lv[2].ksize == 9 && pl->lv[3].ksize == 19 && pl->lv[2].w == 2 * pl->lv[3].w &&
+        pl->lv[2].h == 2 * pl->lv[3].h && w0 >= 64 && h0 >= 64) {
+        bool exact = true;
+        for (int k = 2; k <= 3 && exact; k++) {
+            const LevelPlan& L = pl->lv[k];
+            ResizeTab t;
+            make_resize_tab(w0, h0, L.w, L.h, t);
+            const int sc = 1 << k;
+            exact = t.mode == 1 && t.xmax == L.w && L.w * sc == w0 && L.h * sc == h0;
+            for (int x = 0; x < L.w && exact; x++)
+                exact = t.xofs[x] == sc * x + sc / 2 - 1 && t.alpha[2 * x] == 0.5f && t.alpha[2 * x + 1] == 0.5f;
+            for (int y = 0; y < L.h && exact; y++)
+                exact = t.yofs[y] == sc * y + sc / 2 - 1 && t.beta[2 * y] == 0.5f && t.beta[2 * y + 1] == 0.5f;
+        }
+        if (exact) {
+            pl->fused23 = true;
+            memcpy(pl->k19 + 1, pl->lv[3].h_taps.data(), sizeof(float) * 19);
+            memcpy(pl->k9 + 1, pl->lv[2].h_taps.data(), sizeof(float) * 9);
+        }
+    }
     e->plans[key] = pl;
     *out = pl;
     return TW_OK;
@@ -895,6 +922,34 @@ void launch_pyr(tw_engine* e, hipStream_t st, const Plan* pl, int k, const uint8
         return;
     }
     hipLaunchKernelGGL(tw_pyr_level, grid, dim3(256), lds, st, a);
+}
+
+// levels 3 and 2 of `nimg` images from one read of each image (tw_pyr_23; pl->fused23): I3 / I2 = the level images,
+// z-th at + z * ps of the level
+void launch_pyr23(tw_engine* e, hipStream_t st, const Plan* pl, const uint8_t* const* d_srcs, long long stride, float* I3,
+                  float* I2, int nimg)
+{
+    const LevelPlan &L3 = pl->lv[3], &L2 = pl->lv[2];
+    Pyr23Args a;
+    a.srcs = d_srcs;
+    a.dst3 = I3;
+    a.dst2 = I2;
+    a.zs3 = L3.ps;
+    a.zs2 = L2.ps;
+    a.stride = stride;
+    a.w0 = pl->w0;
+    a.h0 = pl->h0;
+    a.w3 = L3.w;
+    a.h3 = L3.h;
+    a.ld3 = L3.ld;
+    a.w2 = L2.w;
+    a.h2 = L2.h;
+    a.ld2 = L2.ld;
+    a.aligned4 = (stride % 4 == 0) ? e->img_aligned4 : 0;
+    memcpy(a.k19, pl->k19, sizeof(a.k19));
+    memcpy(a.k9, pl->k9, sizeof(a.k9));
+    ProfScope ps(e, st, TW_K_PYR, 3);
+    hipLaunchKernelGGL(tw_pyr_23, dim3((L3.w + P23_T3W - 1) / P23_T3W, (L3.h + P23_T3H - 1) / P23_T3H, nimg), dim3(256), 0, st, a);
 }
 
 tw_status launch_polyexp(tw_engine* e, hipStream_t st, int w, int h, int ld, long long ps, const float* I, float* R,
@@ -1304,8 +1359,18 @@ tw_status flush_ctx(tw_engine* e, Ctx& c)
                     R = e->lat_R + 5 * lat_off[k];
                     if (k < pl->levels && k <= e->lat_s2_max) TW_HIP(e, hipStreamWaitEvent(ls, e->lat_ev[k], 0));
                 } else {
-                    launch_pyr(e, ls, pl, k, e->d_ptrs + 2 * j0, stride, I, 2 * nc);
-                    if ((r = launch_polyexp(e, ls, L.w, L.h, L.ld, L.ps, I, R, 2 * nc, k))) return r;
+                    // levels 3 and 2 from one read of the images (tw_pyr_23): level 3's launch also writes level 2's
+                    // images, behind its own in the workspace (sized for level 0: there is room), and level 2 skips its
+                    // pyramid launch.  Only when both levels cover the same pairs per launch.
+                    // (one launch per level for this lane: the loop is level-major, a second chunk of level 3 would
+                    // overwrite the first chunk's level-2 images before level 2 reads them)
+                    const bool f23 = pl->fused23 && e->pyr_fused && pl->lv[3].chunk >= hi - lo && pl->lv[2].chunk >= hi - lo &&
+                                     (size_t)(pl->lv[3].ps + pl->lv[2].ps) * 2 * nc <= ws_lane;
+                    float* I2side = I + (size_t)pl->lv[3].ps * 2 * nc;
+                    if (f23 && k == 3) launch_pyr23(e, ls, pl, e->d_ptrs + 2 * j0, stride, I, I2side, 2 * nc);
+                    else if (!(f23 && k == 2)) launch_pyr(e, ls, pl, k, e->d_ptrs + 2 * j0, stride, I, 2 * nc);
+                    const float* Isrc = (f23 && k == 2) ? I2side : I;
+                    if ((r = launch_polyexp(e, ls, L.w, L.h, L.ld, L.ps, Isrc, R, 2 * nc, k))) return r;
                 }
                 launch_update(e, ls, pl, k, R, flow_cur, flow_prev, M0, nc);
                 // scan-fused final iteration (option TW_OPT_SCAN_FUSED_FINAL): nothing but the span grid of the last
@@ -1807,6 +1872,8 @@ tw_status tw_engine_create(int device, const tw_params* params, int slots, tw_en
     e->box = (p.flags & 256) ? 0 : 1;
     if (const char* ev = getenv("TW_BLUR_VARIANT")) e->blur_variant = atoi(ev);
     if (const char* ev = getenv("TW_PYR_GENERIC")) e->pyr_generic = atoi(ev);
+    if (const char* ev = getenv("TW_PYR_FUSED")) e->pyr_fused = atoi(ev) != 0;
+    if (e->pyr_generic) e->pyr_fused = 0;
     if (const char* ev = getenv("TW_POLY_VARIANT")) e->poly_variant = atoi(ev);
     if (const char* ev = getenv("TW_BLUR_SMALL")) e->blur_small = atoi(ev);
     if (const char* ev = getenv("TW_BLUR_SMALL_LEVELS")) {
@@ -2369,13 +2436,14 @@ extern "C" int tw_debug_occupancy(char* buf, int cap)
 }
 
 // ---- the yardstick: a plain float4 device copy (SURVEY 8d "measured device-copy peak taken in the same run") -----------
-// One 16-byte load and one 16-byte store per lane and iteration, grid-stride, 8 workgroups of 256 per CU: the same
-// shape MI355X_MICROARCH.md quotes its 6.29 TB/s for, so that bench.py's `frac_of_measured_copy` is comparable with it
-// (a torch copy_ measured 12 % lower in round 4).
+// ONE 16-byte load and one 16-byte store per lane, no loop, one workgroup per 4 KiB: the shape that reaches what
+// MI355X_MICROARCH.md quotes for "float4 copy" (6.29 TB/s there; 6.19 TB/s on round 5's lease, against 4.9 for a
+// grid-stride loop, 4.8 for hipMemcpyDtoD and 5.5 for round 4's torch copy_: tools/ubench/copy_rate.hip,
+// profiles/r05_copy_rate.txt), so that bench.py's `frac_of_measured_copy` is comparable with the guide.
 __global__ __launch_bounds__(256) void tw_copy_f4(const float4* __restrict__ src, float4* __restrict__ dst, size_t n)
 {
-    const size_t stride = (size_t)gridDim.x * 256;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = src[i];
 }
 extern "C" tw_status tw_debug_copy_rate(tw_engine* e, size_t bytes, int reps, double* gbps)
 {
@@ -2387,10 +2455,9 @@ extern "C" tw_status tw_debug_copy_rate(tw_engine* e, size_t bytes, int reps, do
     if (!a || !b) return TW_E_NOMEM;
     hipStream_t st = e->stream;
     TW_HIP(e, hipMemsetAsync(a, 1, bytes, st));
-    hipDeviceProp_t pr;
-    TW_HIP(e, hipGetDeviceProperties(&pr, e->device));
     const size_t n = bytes / 16;
-    const int grid = pr.multiProcessorCount * 8;
+    if ((n + 255) / 256 > 0x7fffffffu) return TW_E_BAD_PARAMETER;
+    const unsigned grid = (unsigned)((n + 255) / 256);
     hipEvent_t ea, eb;
     TW_HIP(e, hipEventCreate(&ea));
     TW_HIP(e, hipEventCreate(&eb));
@@ -2549,6 +2616,37 @@ tw_status tw_stage_pyr_level(tw_engine* e, const uint8_t* img, int w0, int h0, i
     if ((r = down_planes(e, I, d_I, L.ld, L.ps, L.w, L.h, 1))) return r;
     if (w) *w = L.w;
     if (h) *h = L.h;
+    return TW_OK;
+}
+
+tw_status tw_stage_pyr_fused23(tw_engine* e, const uint8_t* img, int w0, int h0, float* I3, float* I2)
+{
+    if (!e || !img || !I3 || !I2) return TW_E_BAD_PARAMETER;
+    TW_HIP(e, hipSetDevice(e->device));
+    Plan* pl = nullptr;
+    tw_status r = get_plan(e, w0, h0, &pl);
+    if (r) return r;
+    if (!pl->fused23) {
+        e->err = "tw_stage_pyr_fused23: levels 2 and 3 of this size are not exact reductions by 4 and 8";
+        return TW_E_UNSUPPORTED;
+    }
+    const LevelPlan &L3 = pl->lv[3], &L2 = pl->lv[2];
+    Tmp t;
+    uint8_t* d_img = t.alloc<uint8_t>((size_t)w0 * h0);
+    float* d_I3 = t.alloc<float>((size_t)L3.ps);
+    float* d_I2 = t.alloc<float>((size_t)L2.ps);
+    const uint8_t** d_tab = t.alloc<const uint8_t*>(1);
+    if (!d_img || !d_I3 || !d_I2 || !d_tab) return TW_E_NOMEM;
+    TW_TRY(h2d_sync(e, d_img, img, (size_t)w0 * h0));
+    const uint8_t* hp = d_img;
+    TW_TRY(h2d_sync(e, (void*)d_tab, &hp, sizeof(hp)));
+    hipStream_t st = e->stream;
+    e->img_aligned4 = 1;  // hipMalloc'ed image, dense rows: the kernel itself checks stride % 4
+    launch_pyr23(e, st, pl, d_tab, w0, d_I3, d_I2, 1);
+    TW_HIP(e, hipGetLastError());
+    TW_HIP(e, hipStreamSynchronize(st));
+    if ((r = down_planes(e, I3, d_I3, L3.ld, L3.ps, L3.w, L3.h, 1))) return r;
+    if ((r = down_planes(e, I2, d_I2, L2.ld, L2.ps, L2.w, L2.h, 1))) return r;
     return TW_OK;
 }
 

@@ -578,6 +578,185 @@ __global__ __launch_bounds__(256) void tw_pyr_taps(PyrTapsArgs aa)
 }
 
 // -----------------------------------------------------------------------------------------------------
+// tw_pyr_23 : K1 for pyramid levels 2 AND 3 of an exact pyr_scale = 0.5 pyramid from ONE read of the u8 image (round 5).
+//   Levels 2 and 3 (9-tap / 19-tap smoothing of the FULL-RES image, INTER_LINEAR down to 1/4 and 1/8) used to be two
+//   launches of tw_pyr_taps over 32 x 8-pixel output tiles: each staged its own 136..274-byte wide region of the same
+//   image (1.9-2.6 x the algorithmic traffic, profiles/r04_pmc_hbm_traffic.md) and ran at 0.09-0.14 of the HBM roofline.
+//   Here a workgroup stages a 252 x 52 byte region ONCE — 64 aligned dwords per row, one coalesced 256-byte row segment
+//   per wave instruction — and produces the 30 x 5 level-3 pixels AND the 60 x 10 level-2 pixels of its 240 x 40 source
+//   tile: row filter at the two source columns each output samples (shared byte window, v_alignbyte + v_cvt_f32_ubyteN,
+//   exactly tw_pyr_taps' scheme) for every staged row, column filter at the two sampled rows, bilinear combine with the
+//   0.5 / 0.5 weights the exact ratio gives.  Same float operations in the same order as tw_pyr_taps / the CPU:
+//   RowFilter left to right, SymmColumnFilter centre-out, (c00*a0 + c01*a1)*b0 + (c10*a0 + c11*a1)*b1.
+//   The host launches it only when its resize tables say xofs[x] = s*x + s/2 - 1, alpha = beta = 0.5 for s = 4 and 8.
+//   Level 3 samples columns 8X+3, 8X+4 (+-9), level 2 columns 4x+1, 4x+2 (+-4); rows alike.
+// -----------------------------------------------------------------------------------------------------
+constexpr int P23_T3W = 30, P23_T3H = 5;          // level-3 tile; level 2: 60 x 10; source: 240 x 40
+constexpr int P23_PD = 66;                        // dwords per staged row (64 + 2: even, so the b64 reads stay aligned)
+constexpr int P23_R3 = 8 * P23_T3H + 12;          // 52 staged rows [r0 - 6, r0 + 46)
+constexpr int P23_R2 = 8 * P23_T3H + 6;           // 46 of them, [r0 - 3, r0 + 43), feed level 2
+struct Pyr23Args {
+    const uint8_t* const* srcs;  // device table of image pointers, one per blockIdx.z
+    float* dst3;                 // level-3 images, z-th at dst3 + z*zs3
+    float* dst2;
+    long long zs3, zs2;
+    long long stride;  // bytes
+    int w0, h0;
+    int w3, h3, ld3, w2, h2, ld2;
+    int aligned4;
+    float k19[24];  // [0, k0 .. k18, 0, ...]: window byte j feeds column X with k19[j+1] and column X+1 with k19[j]
+    float k9[16];   // [0, k0 .. k8, 0, ...]
+};
+
+__global__ __launch_bounds__(256) void tw_pyr_23(Pyr23Args a)
+{
+    __shared__ __attribute__((aligned(16))) unsigned tile[P23_R3][P23_PD];
+    __shared__ __attribute__((aligned(16))) float rb3[P23_R3][2 * P23_T3W];
+    __shared__ __attribute__((aligned(16))) float rb2[P23_R2][4 * P23_T3W];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int bx, by, bz;
+    xcd_remap(bx, by, bz);  // an XCD works on a contiguous band of tiles: the halo rows / cache lines two tiles share hit in its L2
+    const uint8_t* __restrict__ src = a.srcs[bz];
+    const int c0 = bx * (8 * P23_T3W), r0 = by * (8 * P23_T3H);
+
+    // ---- stage the u8 region: rows r0-6 .. r0+45 (REFLECT101), columns c0-8 .. c0+247 as 64 dwords ----
+    {
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(src);
+        const int stride = (int)a.stride;
+        const int col = c0 - 8 + 4 * lane;
+        const bool fast = a.aligned4 && col >= 0 && col + 3 < a.w0;
+        int cc[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) cc[u] = reflect101(col + u, a.w0);
+        constexpr int NR = P23_R3 / 4;  // 13 rows per wave, all loaded before anything is stored
+        unsigned v[NR];
+#pragma unroll
+        for (int u = 0; u < NR; u++) {
+            const int Y = reflect101(r0 - 6 + wv + 4 * u, a.h0);
+            const unsigned ro = (unsigned)(Y * stride);
+            if (fast) {
+                v[u] = __builtin_amdgcn_raw_buffer_load_b32(rs, (unsigned)col + ro, 0, 0);
+            } else {
+                const uint8_t* __restrict__ S = src + ro;
+                v[u] = (unsigned)S[cc[0]] | ((unsigned)S[cc[1]] << 8) | ((unsigned)S[cc[2]] << 16) | ((unsigned)S[cc[3]] << 24);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NR; u++) tile[wv + 4 * u][lane] = v[u];
+    }
+    __syncthreads();
+
+    // ---- row filter, level 3: columns 8x+3 and 8x+4 of output x, every staged row (1 560 tasks) ----
+    for (int t = tid; t < P23_R3 * P23_T3W; t += 256) {
+        const int rr = t / P23_T3W, x = t - rr * P23_T3W;
+        // window = 20 bytes from staged byte 8x+2: dwords 2x .. 2x+5, shifted by 2
+        const u32x2* D = (const u32x2*)&tile[rr][2 * x];
+        const u32x2 d0 = D[0], d1 = D[1], d2 = D[2];
+        const unsigned dw[6] = {d0.x, d0.y, d1.x, d1.y, d2.x, d2.y};
+        float sA = 0.f, sB = 0.f;
+#pragma unroll
+        for (int g = 0; g < 5; g++) {
+            const unsigned wd = __builtin_amdgcn_alignbyte(dw[g + 1], dw[g], 2);
+            const float t0 = (float)(wd & 0xffu), t1 = (float)((wd >> 8) & 0xffu);
+            const float t2 = (float)((wd >> 16) & 0xffu), t3 = (float)(wd >> 24);
+            const float* kk = a.k19 + 4 * g;
+            sA += kk[1] * t0;
+            sB += kk[0] * t0;
+            sA += kk[2] * t1;
+            sB += kk[1] * t1;
+            sA += kk[3] * t2;
+            sB += kk[2] * t2;
+            sA += kk[4] * t3;
+            sB += kk[3] * t3;
+        }
+        f32x2 o2;
+        o2.x = sA;
+        o2.y = sB;
+        *(f32x2*)&rb3[rr][2 * x] = o2;
+    }
+    // ---- row filter, level 2: columns 4x+1 and 4x+2 of output x, staged rows 3 .. 48 (2 760 tasks) ----
+    for (int t = tid; t < P23_R2 * 2 * P23_T3W; t += 256) {
+        const int rr = t / (2 * P23_T3W), x = t - rr * (2 * P23_T3W);
+        // window = 10 bytes from staged byte 4x+5: dwords x+1 .. x+3, shifted by 1 (the bytes past the window weigh 0)
+        const unsigned* D = &tile[rr + 3][x + 1];
+        const unsigned dw[4] = {D[0], D[1], D[2], 0u};
+        float sA = 0.f, sB = 0.f;
+#pragma unroll
+        for (int g = 0; g < 3; g++) {
+            const unsigned wd = __builtin_amdgcn_alignbyte(dw[g + 1], dw[g], 1);
+            const float t0 = (float)(wd & 0xffu), t1 = (float)((wd >> 8) & 0xffu);
+            const float t2 = (float)((wd >> 16) & 0xffu), t3 = (float)(wd >> 24);
+            const float* kk = a.k9 + 4 * g;
+            sA += kk[1] * t0;
+            sB += kk[0] * t0;
+            sA += kk[2] * t1;
+            sB += kk[1] * t1;
+            if (g < 2) {  // window bytes 10, 11 lie past both columns' taps
+                sA += kk[3] * t2;
+                sB += kk[2] * t2;
+                sA += kk[4] * t3;
+                sB += kk[3] * t3;
+            }
+        }
+        f32x2 o2;
+        o2.x = sA;
+        o2.y = sB;
+        *(f32x2*)&rb2[rr][2 * x] = o2;
+    }
+    __syncthreads();
+
+    // ---- column filter at the two sampled rows + bilinear combine ----
+    // both columns of a sample row at once (one 8-byte LDS read per tap row): k0*c + sum k_j*(R[+j] + R[-j])
+    if (tid < P23_T3W * P23_T3H) {
+        const int y = tid / P23_T3W, x = tid - y * P23_T3W;
+        const int ox = bx * P23_T3W + x, oy = by * P23_T3H + y;
+        const float* kc = a.k19 + 1 + 9;
+        f32x2 c[2];
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const float* R = &rb3[8 * y + 9 + q][2 * x];
+            const f32x2 ce = *(const f32x2*)R;
+            float sa = kc[0] * ce.x, sb = kc[0] * ce.y;
+#pragma unroll
+            for (int j = 1; j <= 9; j++) {
+                const f32x2 up = *(const f32x2*)(R + j * (2 * P23_T3W)), dn = *(const f32x2*)(R - j * (2 * P23_T3W));
+                sa += kc[j] * (up.x + dn.x);
+                sb += kc[j] * (up.y + dn.y);
+            }
+            c[q].x = sa;
+            c[q].y = sb;
+        }
+        const float t0 = c[0].x * 0.5f + c[0].y * 0.5f, t1 = c[1].x * 0.5f + c[1].y * 0.5f;
+        if (ox < a.w3 && oy < a.h3) a.dst3[bz * a.zs3 + (long long)oy * a.ld3 + ox] = t0 * 0.5f + t1 * 0.5f;
+    }
+    // level 2: 600 outputs; the third round goes to the threads that had no level-3 pixel
+    for (int i = 0; i < 3; i++) {
+        const int t = i < 2 ? tid + 256 * i : tid - 168 + 512;
+        if (i == 2 && tid < 168) break;
+        const int y = t / (2 * P23_T3W), x = t - y * (2 * P23_T3W);
+        const int ox = bx * (2 * P23_T3W) + x, oy = by * (2 * P23_T3H) + y;
+        const float* kc = a.k9 + 1 + 4;
+        f32x2 c[2];
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const float* R = &rb2[4 * y + 4 + q][2 * x];
+            const f32x2 ce = *(const f32x2*)R;
+            float sa = kc[0] * ce.x, sb = kc[0] * ce.y;
+#pragma unroll
+            for (int j = 1; j <= 4; j++) {
+                const f32x2 up = *(const f32x2*)(R + j * (4 * P23_T3W)), dn = *(const f32x2*)(R - j * (4 * P23_T3W));
+                sa += kc[j] * (up.x + dn.x);
+                sb += kc[j] * (up.y + dn.y);
+            }
+            c[q].x = sa;
+            c[q].y = sb;
+        }
+        const float t0 = c[0].x * 0.5f + c[0].y * 0.5f, t1 = c[1].x * 0.5f + c[1].y * 0.5f;
+        if (ox < a.w2 && oy < a.h2) a.dst2[bz * a.zs2 + (long long)oy * a.ld2 + ox] = t0 * 0.5f + t1 * 0.5f;
+    }
+}
+
+// -----------------------------------------------------------------------------------------------------
 // tw_pyr_k3<MODE> : register-only fast path of K1 for 3-tap smoothing (the two finest levels of a
 //   pyr_scale = 0.5 pyramid: MODE 0 = level 0, same size; MODE 2 = level 1, exact 2x2 area-fast resize).
 //   A thread reads whole dwords of the u8 rows (coalesced), converts with v_cvt_f32_ubyteN and produces

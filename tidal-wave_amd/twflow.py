@@ -52,7 +52,7 @@ SYMBOLS = [
     "tw_last_error", "tw_flow_u8", "tw_diff_u8", "tw_submit_u8", "tw_submit_png8", "tw_submit_dev", "tw_flush", "tw_wait",
     "tw_grid_capacity", "tw_dev_alloc", "tw_dev_free", "tw_dev_upload", "tw_host_alloc", "tw_host_free", "tw_host_register", "tw_host_unregister", "tw_set_option",
     "tw_prof_select", "tw_prof_read",
-    "tw_algorithmic_bytes", "tw_algorithmic_bytes_pair", "tw_min_traffic_bytes_pair", "tw_num_levels", "tw_level_chunk", "tw_bench_stage", "tw_stage_pyr_level",
+    "tw_algorithmic_bytes", "tw_algorithmic_bytes_pair", "tw_min_traffic_bytes_pair", "tw_num_levels", "tw_level_chunk", "tw_bench_stage", "tw_stage_pyr_level", "tw_stage_pyr_fused23",
     "tw_stage_png_unfilter", "tw_stage_polyexp", "tw_stage_update_matrices", "tw_stage_flow_upsample_update", "tw_stage_blur_solve",
     "tw_debug_graphs", "tw_debug_occupancy", "tw_debug_stamps", "tw_debug_copy_rate",
 ]
@@ -144,6 +144,7 @@ def _bind(path):
     L.tw_min_traffic_bytes_pair.restype = C.c_double
     L.tw_num_levels.argtypes = [vp, C.c_int, C.c_int]
     L.tw_stage_pyr_level.argtypes = [vp, u8p, C.c_int, C.c_int, C.c_int, fp, ip, ip]
+    L.tw_stage_pyr_fused23.argtypes = [vp, u8p, C.c_int, C.c_int, fp, fp]
     L.tw_stage_polyexp.argtypes = [vp, fp, C.c_int, C.c_int, fp]
     L.tw_stage_update_matrices.argtypes = [vp, fp, fp, fp, C.c_int, C.c_int, fp]
     L.tw_stage_flow_upsample_update.argtypes = [vp, fp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, fp, fp]
@@ -388,6 +389,16 @@ class Engine:
         w, h = C.c_int(), C.c_int()
         self._check(self._L.tw_stage_pyr_level(self._h, _u8(img), w0, h0, level, _f(buf), C.byref(w), C.byref(h)))
         return buf[: w.value * h.value].reshape(h.value, w.value).copy()
+
+    def stage_pyr_fused23(self, img):
+        """Levels 3 and 2 from the one-read kernel (tw_pyr_23); raises TwError(TW_E_UNSUPPORTED) for sizes without exact
+        reductions by 4 and 8."""
+        img = np.ascontiguousarray(_gray(img))
+        h0, w0 = img.shape
+        I3 = np.empty((h0 // 8, w0 // 8), np.float32)
+        I2 = np.empty((h0 // 4, w0 // 4), np.float32)
+        self._check(self._L.tw_stage_pyr_fused23(self._h, _u8(img), w0, h0, _f(I3), _f(I2)))
+        return I3, I2
 
     def stage_polyexp(self, I):
         I = np.ascontiguousarray(I, np.float32)
