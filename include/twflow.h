@@ -239,6 +239,12 @@ tw_status tw_stage_flow_upsample_update(tw_engine* e, const float* R0_5, const f
                                         float* M5);
 tw_status tw_stage_blur_solve(tw_engine* e, const float* R0_5, const float* R1_5, const float* M5, int w, int h,
                               int update_matrices, float* flow2, float* Mout5);
+/* One whole iteration of the flow update WITHOUT M in memory (tw_flow_iter, round 5): flow_out = solve(window average of
+ * FarnebackUpdateMatrices(R0, R1, flow)) where flow = flow_in2, or (prev2) the coarser level's flow prev2 (pw x ph)
+ * resized INTER_LINEAR to w x h and scaled by 1/pyrScale, or zero (both null).  winSize 30/31 Gaussian window, levels of
+ * at least 320 x 20 pixels; TW_E_UNSUPPORTED otherwise. */
+tw_status tw_stage_flow_iter(tw_engine* e, const float* R0_5, const float* R1_5, const float* flow_in2, const float* prev2,
+                             int pw, int ph, int w, int h, float* flow_out2);
 
 #ifdef __cplusplus
 }

@@ -25,6 +25,10 @@ int tw_debug_occupancy(char* buf, int cap);
  * into out[256]; returns 256, or 0 when no stamps were taken.  No output value of the library depends on them. */
 int tw_debug_stamps(tw_engine* e, unsigned long long* out);
 
+/* The first n (<= 4096) entries of the same buffer: tw_flow_iter's phase stamps in the variants library
+ * ([workgroup 0..31][wave 0 / 9][step 40..47][stamp 0..7]; tools/fi_stamps.py). */
+int tw_debug_stamps_ex(tw_engine* e, unsigned long long* out, int n);
+
 /* The yardstick of bench.py's `frac_of_measured_copy`: `reps` launches of a float4 device-to-device copy kernel over
  * `bytes` (16 B per lane per iteration, grid-stride; read + write counted) on the engine's stream, in GB/s. */
 tw_status tw_debug_copy_rate(tw_engine* e, size_t bytes, int reps, double* gbps);

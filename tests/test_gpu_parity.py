@@ -159,6 +159,67 @@ def test_stage_blur_solve(engine, oracle, h, w, update):
         assert_same(gM, planar(wM), "fused matrix refresh")
 
 
+@pytest.mark.parametrize("h,w", [(117, 320), (270, 480), (135, 333), (64, 700), (540, 960), (23, 321)])
+def test_stage_flow_iter_without_m(engine, oracle, h, w):
+    """Round 5: one whole iteration without M in memory (tw_flow_iter) == FarnebackUpdateMatrices followed
+    by FarnebackUpdateFlow_GaussianBlur of the oracle, bit for bit — strips with ragged right edges (333, 700, 321
+    columns), fewer rows than one ring (23), several row segments, samples pushed out of the image, flat regions."""
+    rng = np.random.default_rng(h * 11 + w)
+    R0, R1, flow = _rand_fields(rng, h, w, mag=2.0)
+    R0[:, h // 2:, w // 2:] = 0   # flat region: det ~ the regulariser
+    R1[:, h // 2:, w // 2:] = 0
+    M = oracle.update_matrices(interleaved(R0), interleaved(R1), interleaved(flow))
+    want, _ = oracle.update_flow(interleaved(R0), interleaved(R1), interleaved(flow), M, 30, 0)
+    got = engine.stage_flow_iter(R0, R1, flow=flow)
+    assert_same(got, planar(want), "M-free iteration %dx%d" % (w, h))
+    # zero input flow (the coarsest level's first iteration)
+    zero = np.zeros_like(flow)
+    M0 = oracle.update_matrices(interleaved(R0), interleaved(R1), interleaved(zero))
+    want0, _ = oracle.update_flow(interleaved(R0), interleaved(R1), interleaved(zero), M0, 30, 0)
+    assert_same(engine.stage_flow_iter(R0, R1), planar(want0), "M-free iteration from zero flow %dx%d" % (w, h))
+
+
+@pytest.mark.parametrize("ph,pw,h,w", [(135, 240, 270, 480), (68, 167, 135, 333), (270, 480, 540, 960)])
+def test_stage_flow_iter_with_fused_upsample(engine, oracle, ph, pw, h, w):
+    """The first iteration of a level: input flow = resize(prevFlow, INTER_LINEAR) * 2 computed inside tw_flow_iter<UPS>."""
+    rng = np.random.default_rng(ph + w)
+    R0, R1, _ = _rand_fields(rng, h, w)
+    prev = (rng.standard_normal((2, ph, pw)) * 2).astype(np.float32)
+    prev[0, 0, 0] = -0.0
+    up = oracle.flow_upsample(interleaved(prev), w, h, 0.5)
+    M = oracle.update_matrices(interleaved(R0), interleaved(R1), up)
+    want, _ = oracle.update_flow(interleaved(R0), interleaved(R1), up, M, 30, 0)
+    assert_same(engine.stage_flow_iter(R0, R1, prev=prev), planar(want), "M-free iteration with upsample %dx%d" % (w, h))
+
+
+def test_pipeline_with_m_free_iterations(twflow, oracle):
+    """TW_MFREE=1: batches of 640x480 and 960x540 pairs run tw_flow_iter at the levels that qualify (>= 320 columns) —
+    flow fields and vectors equal the oracle's, and the default engine's."""
+    import os
+    import synth
+    os.environ["TW_MFREE"] = "1"
+    try:
+        for (h, w) in ((480, 640), (540, 960)):
+            pairs = [synth.make_pair(i, h, w) for i in range(3)]
+            with twflow.Engine(0, twflow.default_params(), slots=4) as e:
+                tk = [e.submit(a, b, 10, 1.0) for a, b in pairs]
+                got = [e.wait(t)["vector"] for t in tk]
+                for (a, b), g in zip(pairs, got):
+                    wx, wy = oracle.farneback(a, b)
+                    assert g == oracle.span_scan(wx, wy, 10, 1.0)
+        # non-default iteration counts: the ping-pong must end in the level's flow buffer for 1, 2 and 4 iterations
+        a, b = synth.make_pair(1, 480, 640)
+        for it in (1, 2, 4):
+            p = twflow.default_params(pyrIterations=it)
+            wx, wy = oracle.farneback(a, b, oracle.default_params(pyrIterations=it))
+            with twflow.Engine(0, p, slots=2) as e:
+                t1, t2 = e.submit(a, b, 10, 0.5), e.submit(b, a, 10, 0.5)
+                assert e.wait(t1)["vector"] == oracle.span_scan(wx, wy, 10, 0.5)
+                e.wait(t2)
+    finally:
+        del os.environ["TW_MFREE"]
+
+
 # ---------------------------------------------------------------------------------------------------
 # whole pipeline
 # ---------------------------------------------------------------------------------------------------

@@ -381,6 +381,9 @@ struct tw_engine {
     int upd_ny = 2;        // TW_UPD_NY: pixels per lane of tw_update_matrices (1 or 2)
     int scan_fused = 0;    // TW_OPT_SCAN_FUSED_FINAL
     int poly_f32 = 0;      // TW_OPT_POLYEXP_F32 (measurement variant: float accumulators, not bit-exact)
+    long long mfree_min_px = 0;  // TW_MFREE_MIN_PX: smallest level (pixels) that takes tw_flow_iter
+    int mfree = 0;         // TW_MFREE=1: levels that qualify run tw_flow_iter (no M in HBM) instead of update + blur launches
+    int cu_count = 256;
     int pyr_fused = 1;     // TW_PYR_FUSED=0: levels 2 and 3 as two tw_pyr_taps launches again (A/B; tw_pyr_23 is the default)
     int pyr_generic = 0;   // TW_PYR_GENERIC=1: always the generic pyramid kernel, 2: tw_pyr_level_lds for every level (A/B)
     int blur_variant = 4;  // 4: tw_blur_solve4 (default); 8: tw_blur_solve8 (packed f32) — TW_BLUR_VARIANT
@@ -1015,6 +1018,82 @@ tw_status launch_polyexp(tw_engine* e, hipStream_t st, int w, int h, int ld, lon
     return TW_OK;
 }
 
+// One whole iteration of the flow update without M in HBM (tw_flow_iter; round 5): flow_out = solve(window average of
+// FarnebackUpdateMatrices(R0, R1, flow_in)).  flow_in: a flow buffer, or (prev != nullptr) the bilinear upsample x
+// 1/pyr_scale of the coarser level's flow computed in place of the load, or zero (both null: the coarsest level).
+bool flow_iter_eligible(const tw_engine* e, int w, int h)
+{
+    return e->win_m == 15 && !e->box && w >= 2 * (FI_SC - 30) && h >= 4 * FI_TH;
+}
+struct FlowUps {  // the coarser level's flow and the resize tables to this level (UpdArgs' upsample fields)
+    const float* prev;
+    int pw, ph, pld;
+    long long pfps;
+    const int *xofs, *yofs;
+    const float *alpha, *beta;
+    int xmax;
+    float scale;
+};
+void launch_flow_iter(tw_engine* e, hipStream_t st, int w, int h, int ld, long long ps, const float* R, const float* flow_in,
+                      long long fps_in, float* flow_out, long long fps_out, const FlowUps* ups, int npairs, int level)
+{
+    FlowIterArgs a;
+    memset(&a, 0, sizeof(a));
+    a.R = R;
+    a.flow_in = flow_in;
+    a.flow_out = flow_out;
+    a.w = w;
+    a.h = h;
+    a.ld = ld;
+    a.ps = ps;
+    a.fps_in = fps_in;
+    a.fps_out = fps_out;
+    a.zero_flow = (!flow_in && !ups) ? 1 : 0;
+    a.c = e->wc;
+    if (const char* ev = getenv("TW_FI_SKIP")) a.dbg_skip = atoi(ev);  // variants library only (timing experiments)
+    a.dbg = (unsigned long long*)e->dbg_stamps;                        // TW_DEBUG_STAMPS=1, variants library only
+    constexpr int OUT = FI_SC - 30;
+    const int nstrips = (w + OUT - 1) / OUT, nsteps = (h + FI_TH - 1) / FI_TH;
+    // Row segments per strip: one 1024-thread workgroup per CU is resident, so the launch runs in rounds of (CU count)
+    // workgroups; a segment pays NCH = 7 chunks of M for its window's warm-up.  Take the split (1 .. 4) with the least
+    // (rounds x (steps + warm-up)) — 128 pairs x 12 strips of 1080p: 2 segments = 12.0 rounds of 108 + 7 steps.
+    int best_seg = 1;
+    double best_cost = 1e300;
+    for (int sg = 1; sg <= 4; sg++) {
+        const int nt = (nsteps + sg - 1) / sg;
+        if (sg > 1 && nt < 16) break;
+        const long long wgs = (long long)nstrips * sg * npairs;
+        const long long rounds = (wgs + e->cu_count - 1) / e->cu_count;
+        const double cost = (double)rounds * (nt + 7 * 0.25);  // a warm-up chunk is a quarter of a step (phase C only)
+        if (cost < best_cost) {
+            best_cost = cost;
+            best_seg = sg;
+        }
+    }
+    a.nt = (nsteps + best_seg - 1) / best_seg;
+    const int nseg = (nsteps + a.nt - 1) / a.nt;
+    const dim3 grid(nstrips, nseg, npairs);
+    ProfScope pscope(e, st, TW_K_BLUR_SOLVE, level);
+    if (ups) {
+        a.prev = ups->prev;
+        a.pw = ups->pw;
+        a.ph = ups->ph;
+        a.pld = ups->pld;
+        a.pfps = ups->pfps;
+        a.xofs = ups->xofs;
+        a.alpha = ups->alpha;
+        a.yofs = ups->yofs;
+        a.beta = ups->beta;
+        a.xmax = ups->xmax;
+        a.scale = ups->scale;
+        hipLaunchKernelGGL((tw_flow_iter<15, 1>), grid, dim3(1024), 0, st, a);
+    } else if (a.zero_flow) {
+        hipLaunchKernelGGL((tw_flow_iter<15, 2>), grid, dim3(1024), 0, st, a);
+    } else {
+        hipLaunchKernelGGL((tw_flow_iter<15, 0>), grid, dim3(1024), 0, st, a);
+    }
+}
+
 void launch_blur(tw_engine* e, hipStream_t st, int w, int h, int ld, long long ps, const float* Min, float* Mout,
                  float* flow, const float* R, int update, int level, int npairs, double* Vbox = nullptr)
 {
@@ -1372,11 +1451,32 @@ tw_status flush_ctx(tw_engine* e, Ctx& c)
                     const float* Isrc = (f23 && k == 2) ? I2side : I;
                     if ((r = launch_polyexp(e, ls, L.w, L.h, L.ld, L.ps, Isrc, R, 2 * nc, k))) return r;
                 }
-                launch_update(e, ls, pl, k, R, flow_cur, flow_prev, M0, nc);
+                // M-free iterations (tw_flow_iter; TW_MFREE): the level's iterations read the previous flow and recompute M
+                // inside the kernel — no FarnebackUpdateMatrices launch, no M planes.  Flows ping-pong between the level's
+                // flow buffer and the (now unused) M0 workspace so that the last iteration lands in the flow buffer.
                 // scan-fused final iteration (option TW_OPT_SCAN_FUSED_FINAL): nothing but the span grid of the last
                 // level-0 flow is read afterwards, so the last window average + solve runs at the grid points only
                 const bool grid_only = k == 0 && it > 0 && e->scan_fused && c.span == 10 && e->win_m == 15 && !e->box;
-                for (int i = 0; i < it; i++) {
+                bool iterated = false;
+                if (e->mfree && !lat && it > 0 && !grid_only && flow_iter_eligible(e, L.w, L.h) &&
+                    (e->mfree_min_px <= 0 || (long long)L.w * L.h >= e->mfree_min_px)) {
+                    float* buf[2] = {flow_cur, M0};  // iteration i writes buf[(it - 1 - i) & 1]
+                    FlowUps ups;
+                    if (k < pl->levels) {
+                        const LevelPlan& Pv = pl->lv[k + 1];
+                        ups = FlowUps{flow_prev, Pv.w, Pv.h, Pv.ld, Pv.ps, L.d_uxofs, L.d_uyofs, L.d_ualpha, L.d_ubeta, L.uxmax,
+                                      (float)(1. / e->p.pyrScale)};
+                    }
+                    for (int i = 0; i < it; i++) {
+                        float* out = buf[(it - 1 - i) & 1];
+                        const float* in = i == 0 ? nullptr : buf[(it - i) & 1];
+                        launch_flow_iter(e, ls, L.w, L.h, L.ld, L.ps, R, in, L.ps, out, L.ps,
+                                         (i == 0 && k < pl->levels) ? &ups : nullptr, nc, k);
+                    }
+                    iterated = true;
+                }
+                if (!iterated) launch_update(e, ls, pl, k, R, flow_cur, flow_prev, M0, nc);
+                for (int i = 0; i < it && !iterated; i++) {
                     if (grid_only && i == it - 1) {
                         BlurGridArgs g;
                         g.Min = (i & 1) ? M1 : M0;
@@ -1873,6 +1973,12 @@ tw_status tw_engine_create(int device, const tw_params* params, int slots, tw_en
     if (const char* ev = getenv("TW_BLUR_VARIANT")) e->blur_variant = atoi(ev);
     if (const char* ev = getenv("TW_PYR_GENERIC")) e->pyr_generic = atoi(ev);
     if (const char* ev = getenv("TW_PYR_FUSED")) e->pyr_fused = atoi(ev) != 0;
+    if (const char* ev = getenv("TW_MFREE")) e->mfree = atoi(ev);
+    if (const char* ev = getenv("TW_MFREE_MIN_PX")) e->mfree_min_px = atoll(ev);
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) e->cu_count = cus;
+    }
     if (e->pyr_generic) e->pyr_fused = 0;
     if (const char* ev = getenv("TW_POLY_VARIANT")) e->poly_variant = atoi(ev);
     if (const char* ev = getenv("TW_BLUR_SMALL")) e->blur_small = atoi(ev);
@@ -1905,7 +2011,8 @@ tw_status tw_engine_create(int device, const tw_params* params, int slots, tw_en
     }
 #endif
     if (const char* ev = getenv("TW_DEBUG_STAMPS"))
-        if (atoi(ev)) (void)hipMalloc((void**)&e->dbg_stamps, 64 * 4 * sizeof(unsigned long long));
+        if (atoi(ev) && hipMalloc((void**)&e->dbg_stamps, 4096 * sizeof(unsigned long long)) == hipSuccess)
+            (void)hipMemset(e->dbg_stamps, 0, 4096 * sizeof(unsigned long long));
     if (const char* ev = getenv("TW_UPD_NY")) e->upd_ny = atoi(ev) == 1 ? 1 : 2;
     if (const char* ev = getenv("TW_LANES")) e->lanes = std::min(2, std::max(1, atoi(ev)));
     if (const char* ev = getenv("TW_LATENCY_STREAMS")) e->lat_streams = atoi(ev) ? 1 : 0;
@@ -2409,6 +2516,15 @@ extern "C" int tw_debug_stamps(tw_engine* e, unsigned long long* out)
     return d2h_sync(e, out, e->dbg_stamps, 64 * 4 * sizeof(unsigned long long)) == TW_OK ? 256 : 0;
 }
 
+// the first n (<= 4096) stamps of the debug buffer: tw_flow_iter's phase stamps (variants library, TW_DEBUG_STAMPS=1):
+// [workgroup 0..31][wave 0 / 9][step 40..47][stamp 0..7]
+extern "C" int tw_debug_stamps_ex(tw_engine* e, unsigned long long* out, int n)
+{
+    if (!e || !e->dbg_stamps || !out || n < 1 || n > 4096) return 0;
+    if (hipSetDevice(e->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return 0;
+    return d2h_sync(e, out, e->dbg_stamps, (size_t)n * sizeof(unsigned long long)) == TW_OK ? n : 0;
+}
+
 // number of captured single-pair schedules this engine holds (tests: the graph path is really the one that ran)
 extern "C" int tw_debug_graphs(tw_engine* e) { return e ? (int)e->lat_graphs.size() : -1; }
 
@@ -2556,6 +2672,21 @@ extern "C" tw_status tw_bench_stage(tw_engine* e, int kclass, int width, int hei
             case TW_K_POLYEXP: return launch_polyexp(e, st, L.w, L.h, L.ld, L.ps, I, R, 2 * npairs, level);
             case TW_K_UPDATE_MATRICES: launch_update(e, st, pl, level, R, fl, pf, M0, npairs); break;
             case TW_K_BLUR_SOLVE:
+                if (flags & 12) {
+                    // flags 4: one M-free iteration (tw_flow_iter) from the synthetic flow field into the M1 workspace;
+                    // flags 8: the same with the upsample of the coarser level's flow fused (first iteration of a level)
+                    if (!flow_iter_eligible(e, L.w, L.h)) return TW_E_UNSUPPORTED;
+                    FlowUps ups;
+                    const bool up = (flags & 8) && level < pl->levels;
+                    if (up) {
+                        const LevelPlan& Pv = pl->lv[level + 1];
+                        ups = FlowUps{pf, Pv.w, Pv.h, Pv.ld, Pv.ps, L.d_uxofs, L.d_uyofs, L.d_ualpha, L.d_ubeta, L.uxmax,
+                                      (float)(1. / e->p.pyrScale)};
+                    }
+                    launch_flow_iter(e, st, L.w, L.h, L.ld, L.ps, R, up ? nullptr : fl, L.ps, M1, L.ps, up ? &ups : nullptr,
+                                     npairs, level);
+                    break;
+                }
                 launch_blur(e, st, L.w, L.h, L.ld, L.ps, (i & 1) ? M1 : M0, (i & 1) ? M0 : M1, fl, R, (flags & 2) ? 0 : 1,
                             level, npairs);
                 break;
@@ -2819,6 +2950,49 @@ tw_status tw_stage_blur_solve(tw_engine* e, const float* R0_5, const float* R1_5
     if ((r = down_planes(e, flow2, d_f, ld, ps, w, h, 2))) return r;
     if (update_matrices) return down_planes(e, Mout5, d_Mo, ld, ps, w, h, 5);
     return TW_OK;
+}
+
+tw_status tw_stage_flow_iter(tw_engine* e, const float* R0_5, const float* R1_5, const float* flow_in2, const float* prev2,
+                             int pw, int ph, int w, int h, float* flow_out2)
+{
+    if (!e || !R0_5 || !R1_5 || !flow_out2 || w < 1 || h < 1 || (flow_in2 && prev2)) return TW_E_BAD_PARAMETER;
+    if (!flow_iter_eligible(e, w, h)) {
+        e->err = "tw_stage_flow_iter: winSize 30/31 Gaussian window and a level of at least 320 x 20 pixels";
+        return TW_E_UNSUPPORTED;
+    }
+    TW_HIP(e, hipSetDevice(e->device));
+    const int ld = round_up(w, 32);
+    const long long ps = (long long)ld * h;
+    const int pld = prev2 ? round_up(pw, 32) : 0;
+    const long long pps = (long long)pld * ph;
+    Tmp t;
+    float *d_R = t.alloc<float>(ps * 10), *d_fi = t.alloc<float>(ps * 2), *d_fo = t.alloc<float>(ps * 2);
+    if (!d_R || !d_fi || !d_fo) return TW_E_NOMEM;
+    tw_status r;
+    if ((r = up_planes(e, d_R, ld, ps, R0_5, w, h, 5)) || (r = up_planes(e, d_R + 5 * ps, ld, ps, R1_5, w, h, 5))) return r;
+    if (flow_in2 && (r = up_planes(e, d_fi, ld, ps, flow_in2, w, h, 2))) return r;
+    FlowUps ups;
+    if (prev2) {
+        if (pw < 1 || ph < 1) return TW_E_BAD_PARAMETER;
+        ResizeTab u;
+        make_resize_tab(pw, ph, w, h, u);
+        if (u.mode == 2) return TW_E_UNSUPPORTED;
+        float* d_p = t.alloc<float>(pps * 2);
+        int *d_xo = t.alloc<int>(w), *d_yo = t.alloc<int>(h);
+        float *d_al = t.alloc<float>(2 * (size_t)w), *d_be = t.alloc<float>(2 * (size_t)h);
+        if (!d_p || !d_xo || !d_yo || !d_al || !d_be) return TW_E_NOMEM;
+        if ((r = up_planes(e, d_p, pld, pps, prev2, pw, ph, 2))) return r;
+        TW_TRY(h2d_sync(e, d_xo, u.xofs.data(), (size_t)w * 4));
+        TW_TRY(h2d_sync(e, d_yo, u.yofs.data(), (size_t)h * 4));
+        TW_TRY(h2d_sync(e, d_al, u.alpha.data(), (size_t)w * 8));
+        TW_TRY(h2d_sync(e, d_be, u.beta.data(), (size_t)h * 8));
+        ups = FlowUps{d_p, pw, ph, pld, pps, d_xo, d_yo, d_al, d_be, u.xmax, (float)(1. / e->p.pyrScale)};
+    }
+    hipStream_t st = e->stream;
+    launch_flow_iter(e, st, w, h, ld, ps, d_R, flow_in2 ? d_fi : nullptr, ps, d_fo, ps, prev2 ? &ups : nullptr, 1, -1);
+    TW_HIP(e, hipGetLastError());
+    TW_HIP(e, hipStreamSynchronize(st));
+    return down_planes(e, flow_out2, d_fo, ld, ps, w, h, 2);
 }
 
 }  // extern "C"

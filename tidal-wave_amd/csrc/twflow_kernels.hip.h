@@ -1834,6 +1834,389 @@ __global__ __launch_bounds__(COLS) __attribute__((amdgpu_waves_per_eu(4, 8))) vo
     }
 }
 
+// -----------------------------------------------------------------------------------------------------
+// tw_flow_iter<MH, UPS> (round 5) : ONE WHOLE ITERATION of the flow update without M in HBM.
+//   The reference's iteration is  M = FarnebackUpdateMatrices(R0, R1, flow)  ->  window average of M  ->  2x2 solve -> flow'
+//   (optflowgf.cpp FarnebackUpdateFlow_GaussianBlur; the stripe-wise refresh is "whole new M from the whole new flow").
+//   tw_blur_solve4 moves M across HBM twice per iteration (20 B/px in, 20 out, + R0 20 + R1 20 = 80 B/px).  M is a pure
+//   function of R0(x), R1 around x + flow(x) and flow(x): this kernel reads the PREVIOUS FLOW (8 B/px) instead, recomputes
+//   every M row exactly once and keeps the 2*MH + TH rows the window needs in an LDS ring — 56 B/px per iteration (flow 8 +
+//   R0 20 + R1 20 in, flow' 8 out), no separate first-update launch per level (profiles/r04_m_free_iteration.md: the
+//   memory shape replays at 29.9 us per 1080p pair against 42.1).
+//   A 1024-thread workgroup (one per CU: 150 KB of LDS) marches down a strip of SC = 190 columns (OUT = 160 outputs + MH
+//   halo columns either side) in steps of TH = 5 rows:
+//     blk[8][5][TH][.]        eight equal LDS blocks; chunk k (TH = 5 rows of M, 5 planes) lives in block k % 8, the window of a
+//                             step is 7 chunks (rows y0 - MH .. y0 + TH + MH - 1), the eighth block is the spare
+//     phase A (15 waves)      V: thread (plane, column) reads its 35-row window (static LDS offsets: the block rotation is an
+//                             8-way wave-uniform switch) and writes the TH vertical sums to the spare block X — float,
+//                             centre-out pair order, exactly tw_blur_solve4's V.
+//     barrier
+//     phase B1 (1 000 thr.)   H: thread (plane, row, 4-pixel group) reads a 36-value window of X (ds_read_b128), horizontal
+//                             sums in tw_blur_solve4's order, into block Y = the block of the chunk this step retires.
+//     barrier
+//     phase B2                C (950 threads): FarnebackUpdateMatrices of the chunk the next step needs (update_matrices_combine:
+//                             the same function the other kernels use) into X, from loads issued a whole step earlier — and
+//                             at once the loads of the chunk after it (R0, the 2x2 taps of R1 at x + flow, the flow one chunk
+//                             further on) into the registers just freed: the HBM streams all the time, nothing waits for it;
+//                             S (800 threads): one pixel from Y, 2x2 solve in double, flow store.
+//     barrier
+//   (A first version did H + S as 400 (row, 2-pixel, all planes) items next to C in one phase: two barriers per step, but
+//   only two busy waves per SIMD for most of that phase — 44 % VALU utilisation, 49.8 us per 1080p pair; gpurun_out/r5d.)
+//   Borders need no special case: M at a replicated row / column IS M at the clamped coordinate (the vertical sum of a
+//   replicated column is the sum of the clamped column), so phase C clamps (x, y) and everything downstream is uniform.
+//   UPS: the iteration's input flow is the bilinear upsample * (1/pyr_scale) of the coarser level's flow (first iteration of
+//   a level: what tw_update_matrices<true> fuses), computed in place of the flow load; zero_flow: the coarsest level.
+// -----------------------------------------------------------------------------------------------------
+constexpr int FI_TH = 5, FI_SC = 190, FI_PITCH = 192;
+struct FlowIterArgs {
+    const float* R;        // pair z: R0 = R + (2z)*5ps, R1 = R0 + 5ps
+    const float* flow_in;  // pair z: 2 planes at flow_in + z*2*fps_in
+    float* flow_out;       // pair z: 2 planes at flow_out + z*2*fps_out
+    int w, h, ld;
+    long long ps, fps_in, fps_out;
+    int nt;         // steps (of FI_TH rows) per workgroup; grid.y segments cover the rows
+    int zero_flow;  // input flow = 0 (coarsest level), nothing is read
+    // UPS: upsample source (the coarser level's final flow) and its resize tables, as UpdArgs
+    const float* prev;
+    int pw, ph, pld;
+    long long pfps;
+    const int* xofs;
+    const float* alpha;
+    const int* yofs;
+    const float* beta;
+    int xmax;
+    float scale;
+    unsigned long long* dbg;  // measurement builds (TW_VARIANTS): s_memtime stamps of steps 40-47 of the first 32 workgroups
+    int dbg_skip;  // measurement builds (TW_VARIANTS, TW_FI_SKIP): 1 no C (combine), 4 no H, 8 no S — timing only
+    WinCoef c;
+};
+
+#ifdef TW_VARIANTS
+#define TW_FI_SKIP(bit) (a.dbg_skip & (bit))
+// stamp i (0..7) of step st, waves 0 and 9, workgroups 0..31 (linear block id), steps 40..47
+#define TW_FI_STAMP(i)                                                                                                   \
+    do {                                                                                                                 \
+        if (a.dbg && (tid == 0 || tid == 576) && fi_blin < 32 && st >= 40 && st < 48)                                      \
+            a.dbg[(((size_t)fi_blin * 2 + (tid ? 1 : 0)) * 8 + (st - 40)) * 8 + (i)] = __builtin_amdgcn_s_memtime();       \
+    } while (0)
+#else
+#define TW_FI_SKIP(bit) false
+#define TW_FI_STAMP(i) do { } while (0)
+#endif
+// MODE 0: input flow from flow_in; 1: the coarser level's flow, upsampled in place of the load (UPS); 2: zero flow (no
+// load at all).  A template parameter, not a runtime flag: with the three sources behind one join the compiler copied the
+// freshly loaded flow into the loop-carried registers AFTER the join — an s_waitcnt vmcnt(0) on loads issued a few
+// instructions earlier, in every step.
+template <int MH, int MODE>
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) void tw_flow_iter(FlowIterArgs a)
+{
+    constexpr bool UPS = MODE == 1;
+    constexpr int TH = FI_TH, SC = FI_SC, P = FI_PITCH, OUT = SC - 2 * MH, RING = TH + 2 * MH, NCH = RING / TH, NB = NCH + 1;
+    static_assert(RING % TH == 0 && SC <= P && TH * SC <= 1024 && TH == 5 && OUT % 4 == 0 && 5 * TH * (OUT / 4) <= 1024 && (NB & (NB - 1)) == 0, "geometry");
+    // NB = 8 equal blocks of [plane][row][column]: chunk k of M lives in block k % 8; the eighth block is the spare that
+    // takes the vertical sums of a step, and the block of the chunk a step retires takes its horizontal sums:
+    //   step st:  V reads chunks st .. st+6 (blocks (st+j) % 8) and writes block X = (st+7) % 8;  H reads X and writes
+    //   block Y = st % 8 (chunk st is dead);  S reads Y while C writes chunk st+7 into X — no two phases touch one block.
+    __shared__ __attribute__((aligned(16))) float blk[NB][5][TH][P];
+    const int tid = threadIdx.x;
+    int bx, seg, z;
+    xcd_remap(bx, seg, z);
+    const unsigned fi_blin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    (void)fi_blin;
+    const WinCoef& c = a.c;
+    const float* __restrict__ R0 = a.R + (long long)(2 * z) * 5 * a.ps;
+    const float* __restrict__ R1 = R0 + 5 * a.ps;
+    const float* __restrict__ fin = a.flow_in + (long long)z * 2 * a.fps_in;
+    float* __restrict__ fout = a.flow_out + (long long)z * 2 * a.fps_out;
+    // thread = (row cr of a chunk, strip column cc) in phase C and = (plane cr, column cc) in phase A (TH == 5 planes)
+    const bool cth = tid < TH * SC;
+    const int cr = cth ? tid / SC : 0, cc = cth ? tid - cr * SC : 0;
+    const int xc = clampi(bx * OUT - MH + cc, 0, a.w - 1);
+    const int ys = seg * a.nt * TH;
+    const int nsteps = min(a.nt, (a.h - ys + TH - 1) / TH);
+    if (nsteps <= 0) return;
+
+    // ---- the input flow of the pixel (xc, clamp(y)) of chunk k, row cr ----
+    // UPS: resize(prevFlow, INTER_LINEAR) * scale as tw_update_matrices<true> computes it; the column's taps are fixed
+    int sx = 0, sx1 = 0;
+    bool two = false;
+    float ua0 = 0.f, ua1 = 0.f;
+    if (UPS) {
+        sx = a.xofs[xc];
+        sx1 = min(sx + 1, a.pw - 1);
+        two = xc < a.xmax;
+        ua0 = a.alpha[2 * xc];
+        ua1 = a.alpha[2 * xc + 1];
+    }
+    const float* __restrict__ prev = UPS ? a.prev + (long long)z * 2 * a.pfps : nullptr;
+    struct FlowIn {
+        float p[UPS ? 8 : 2];
+        float b0, b1;
+    };
+    auto row_of = [&](int k) { return clampi(ys - MH + TH * k + cr, 0, a.h - 1); };
+    // UPS: the row's resize entry (yofs, beta) is a table lookup the coarse taps' addresses depend on: it is fetched one
+    // chunk ahead of the taps (ysy / yb0 / yb1 hold the entry of the NEXT flow_issue's row), or every step would wait
+    // for an L2 round trip behind the R0 loads it has just issued
+    int ysy = 0;
+    float yb0 = 0.f, yb1 = 0.f;
+    auto ytab_issue = [&](int k) {
+        if constexpr (UPS) {
+            const int yc = row_of(k);
+            ysy = a.yofs[yc];
+            yb0 = a.beta[2 * yc];
+            yb1 = a.beta[2 * yc + 1];
+        }
+    };
+    auto flow_issue = [&](int k, FlowIn& f) {
+        const int yc = row_of(k);
+        if constexpr (UPS) {
+            int sy;
+            asm volatile("v_mov_b32 %0, %3\n\tv_mov_b32 %1, %4\n\tv_mov_b32 %2, %5"
+                         : "=&v"(sy), "=&v"(f.b0), "=&v"(f.b1)
+                         : "v"(ysy), "v"(yb0), "v"(yb1));
+            const int r0 = clampi(sy, 0, a.ph - 1), r1 = clampi(sy + 1, 0, a.ph - 1);
+            const float* P0 = prev + (long long)r0 * a.pld;
+            const float* P1 = prev + (long long)r1 * a.pld;
+            f.p[0] = P0[sx];
+            f.p[1] = P0[sx1];
+            f.p[2] = P1[sx];
+            f.p[3] = P1[sx1];
+            f.p[4] = P0[a.pfps + sx];
+            f.p[5] = P0[a.pfps + sx1];
+            f.p[6] = P1[a.pfps + sx];
+            f.p[7] = P1[a.pfps + sx1];
+        } else if constexpr (MODE == 2) {
+            f.p[0] = f.p[1] = 0.f;
+        } else {
+            const long long o = (long long)yc * a.ld + xc;
+            f.p[0] = fin[o];
+            f.p[1] = fin[o + a.fps_in];
+        }
+    };
+    auto flow_value = [&](const FlowIn& f, float& dx, float& dy) {
+        if constexpr (UPS) {
+            // dx >= xmax: HResizeLinear's single-tap tail (S[sx] * 1)
+            const float t0x = two ? f.p[0] * ua0 + f.p[1] * ua1 : f.p[0] * 1.f;
+            const float t1x = two ? f.p[2] * ua0 + f.p[3] * ua1 : f.p[2] * 1.f;
+            const float t0y = two ? f.p[4] * ua0 + f.p[5] * ua1 : f.p[4] * 1.f;
+            const float t1y = two ? f.p[6] * ua0 + f.p[7] * ua1 : f.p[6] * 1.f;
+            dx = (t0x * f.b0 + t1x * f.b1) * a.scale + 0.f;
+            dy = (t0y * f.b0 + t1y * f.b1) * a.scale + 0.f;
+        } else {
+            // explicit moves, here: left to the register allocator the copies land AFTER the next flow load has been
+            // issued, the load then needs registers of its own and its result is moved into the loop-carried pair behind
+            // an s_waitcnt that stalls every wave on a load it issued a few instructions earlier
+            asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=&v"(dx), "=&v"(dy) : "v"(f.p[0]), "v"(f.p[1]));
+        }
+    };
+    // R0 and the 2x2 taps of R1 at (xc, yc) + flow: loads only (update_matrices_gather_s with the ten plane bases pinned
+    // to SGPR pairs once, here, in uniform control flow: 27 loads share three 32-bit offset registers)
+    gptr_cf r0b[5], r1b[5];
+#pragma unroll
+    for (int ch = 0; ch < 5; ch++) {
+        r0b[ch] = sgpr_base(R0 + ch * a.ps);
+        r1b[ch] = sgpr_base(R1 + ch * a.ps);
+    }
+    // In pieces, so that the steady loop can spread them over a step (see there): the addresses + R0, then one plane of taps each
+    unsigned go0 = 0, go1 = 0;
+    unsigned gq = 0;
+    auto gather_r0 = [&](int ch, float q[5]) { q[ch] = gload(r0b[ch], gq); };
+    auto gather_head = [&](int k, float dx, float dy, float q[5], UpdTaps& T, bool with_r0) {
+        const int yc = row_of(k);
+        gq = (unsigned)(yc * a.ld + xc) * 4u;
+        if (with_r0) {
+#pragma unroll
+            for (int ch = 0; ch < 5; ch++) gather_r0(ch, q);
+        }
+        const float fx = (float)xc + dx, fy = (float)yc + dy;
+        const float flx = floorf(fx), fly = floorf(fy);
+        const bool inb = flx >= 0.f && flx < (float)(a.w - 1) && fly >= 0.f && fly < (float)(a.h - 1);
+        const int x1 = inb ? (int)flx : 0, y1 = inb ? (int)fly : 0;
+        T.fx = fx - (float)x1;
+        T.fy = fy - (float)y1;
+        T.inb = inb;
+        go0 = (unsigned)(y1 * a.ld + x1) * 4u;
+        go1 = go0 + (unsigned)a.ld * 4u;
+    };
+    // the two taps of a row are adjacent: ONE 8-byte load at 4-byte alignment each (10 instead of 20 tap instructions per
+    // pixel: the memory pipe's cost is per wave-instruction — ~11.6 cycles each when it is the only thing running)
+    typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
+    typedef const f32x2u __attribute__((address_space(1))) * gptr_c2u;
+    auto gather_plane = [&](int ch, UpdTaps& T) {
+        const f32x2u t01 = *(gptr_c2u)((gptr_cc)r1b[ch] + go0);
+        const f32x2u t23 = *(gptr_c2u)((gptr_cc)r1b[ch] + go1);
+        T.t[ch][0] = t01.x;
+        T.t[ch][1] = t01.y;
+        T.t[ch][2] = t23.x;
+        T.t[ch][3] = t23.y;
+    };
+    auto gather_issue = [&](int k, float dx, float dy, float q[5], UpdTaps& T) {
+        gather_head(k, dx, dy, q, T, true);
+#pragma unroll
+        for (int ch = 0; ch < 5; ch++) gather_plane(ch, T);
+    };
+    auto combine_store = [&](int k, float dx, float dy, const float q[5], const UpdTaps& T) {
+        float M[5];
+        update_matrices_combine(q, T, a.w, a.h, xc, row_of(k), dx, dy, M);
+#pragma unroll
+        for (int ch = 0; ch < 5; ch++) blk[k % NB][ch][cr][cc] = M[ch];
+    };
+
+    // ---- prologue: chunks 0 .. NCH-1 (rows ys - MH .. ys + TH + MH - 1) ----
+    FlowIn fcur, fnext;
+    float q[5];
+    UpdTaps T;
+    float dx = 0.f, dy = 0.f;
+    if (cth) {
+        ytab_issue(0);
+        flow_issue(0, fcur);
+        ytab_issue(1);
+#pragma unroll 1
+        for (int k = 0; k < NCH; k++) {
+            flow_issue(k + 1, fnext);
+            ytab_issue(k + 2);
+            flow_value(fcur, dx, dy);
+            gather_issue(k, dx, dy, q, T);
+            combine_store(k, dx, dy, q, T);
+            fcur = fnext;
+        }
+        flow_value(fnext, dx, dy);
+        gather_head(NCH, dx, dy, q, T, true);
+        flow_issue(NCH + 1, fnext);
+        ytab_issue(NCH + 2);
+        // fnext = input flow of chunk NCH + 1; chunk NCH's head is in flight.  From here on ONE flow
+        // variable is carried: its arrived value is consumed into dx / dy, then the next load is issued into the same
+        // registers — with a second variable copied from it the compiler waited for the load it had just issued,
+        // vmcnt(0), before the copy.
+    }
+    __syncthreads();
+
+    // H thread: (plane hp, row hr, 4-pixel group hq) — 1 000 of the 1 024 threads; S thread: one output pixel (sr, sc)
+    constexpr int NQ = OUT / 4;
+    const bool hth = tid < 5 * TH * NQ;
+    const int hp = hth ? tid / (TH * NQ) : 0, hrem = hth ? tid - hp * (TH * NQ) : 0, hr = hrem / NQ, hq = hrem - hr * NQ;
+    const bool sth = tid < TH * OUT;
+    const int sr = sth ? tid / OUT : 0, sc = sth ? tid - sr * OUT : 0;
+    const int sxo = bx * OUT + sc;
+
+#pragma unroll 1
+    for (int st = 0; st < nsteps; st++) {
+        const bool more = st + 1 < nsteps;  // V(st + 1) will run: it needs chunk st + NCH
+        const int s0 = st & (NB - 1), bX = (st + NCH) & (NB - 1);
+        TW_FI_STAMP(0);
+        // ---- phase A: V(st) -> block X, with the loads of chunk st + NCH spread through it ----
+        // The memory side of a step (56 B/px + the halo columns: 22.6 us per 1080p pair alone, HBM-bound at 6.1 TB/s) and its
+        // arithmetic (V + H + S: 26.7 us alone) only overlap if requests are QUEUED all through the arithmetic.  Issued in
+        // one piece — at the start of this phase, or right after the previous chunk's combine — the 405 wave-loads of a
+        // step block their waves at the issue (the memory pipe buffers a fraction of them) until most are served, and
+        // the arithmetic phases then run with an idle HBM: 49 us, the plain sum (gpurun_out/r5h).  So: addresses, R0 and the
+        // next chunk's flow before V's first row, one plane of taps after each row.
+        // Schedule of the 17 loads of a pixel, a few at a time: the addresses and three R0 planes right after the previous
+        // chunk's combine in phase B2, the other two and the next chunk's flow behind S, the two 8-byte tap loads of plane r
+        // behind V's row r.  (In-kernel stamps, tools/fi_stamps.py: issued in bursts — 7 or 8 loads by all 15 waves at once
+        // — a burst blocked every wave for ~1 450 cycles at the issue, with the VALUs idle.)
+        // All UNCONDITIONAL for the threads that run V (in the last step of a segment they fetch a chunk nobody needs — row_of
+        // clamps it into the image): a conditional load joins with "no load" in a copy of the loaded register, and the
+        // compiler waits for the load, vmcnt(0), right where it issued it.
+        if (cth) {
+            // The window's chunk j (rows TH*j .. TH*j + TH - 1) sits in block (s0 + j) % NB: the block offsets are wave-uniform
+            // (scalar), so a chunk costs one vector add for its address and its TH rows are immediate offsets — no code per
+            // rotation.  (An 8-way switch over s0 with the loads AND sums per case compiled without spills, but once global
+            // loads were interleaved with the rows the compiler hoisted / joined them across the cases and waited for them
+            // in place.)
+            float wv[RING];
+#pragma unroll
+            for (int j = 0; j < NCH; j++) {
+                const float* bj = &blk[(s0 + j) & (NB - 1)][cr][0][cc];
+#pragma unroll
+                for (int r = 0; r < TH; r++) wv[TH * j + r] = bj[r * P];
+            }
+            float* vout = &blk[bX][cr][0][cc];
+#pragma unroll
+            for (int r = 0; r < TH; r++) {
+                float sv = wv[r + MH] * c.k[0];
+#pragma unroll
+                for (int i = 1; i <= MH; i++) sv += (wv[r + MH + i] + wv[r + MH - i]) * c.k[i];
+                vout[r * P] = sv;
+                __builtin_amdgcn_sched_barrier(0);
+                if (r < 3) gather_plane(r, T);  // (the taps of planes 0-2 behind rows 0-2; planes 3, 4 inside H)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        TW_FI_STAMP(1);
+        __syncthreads();
+        TW_FI_STAMP(2);
+
+        // ---- phase B1: H — (plane, row, 4-pixel group): 36-value window from block X, four sums into block Y ----
+        if (hth && !TW_FI_SKIP(4)) {
+            float v[4 + 2 * MH + 2];
+            const f32x4* W4 = (const f32x4*)&blk[bX][hp][hr][4 * hq];
+#pragma unroll
+            for (int u = 0; u < (4 + 2 * MH + 2) / 4; u++) {
+                const f32x4 t = W4[u];
+                v[4 * u] = t[0];
+                v[4 * u + 1] = t[1];
+                v[4 * u + 2] = t[2];
+                v[4 * u + 3] = t[3];
+            }
+            f32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int li = MH + j;
+                float sum = v[li] * c.k[0];
+#pragma unroll
+                for (int i = 1; i <= MH; i++) sum += c.k[i] * (v[li - i] + v[li + i]);
+                o[j] = sum;
+                __builtin_amdgcn_sched_barrier(0);
+                // (every H thread: the 50 that have no pixel in phase C load from offset 0 of the plane — valid, unused —
+                // rather than make the load conditional: see above)
+                if (j < 2) gather_plane(3 + j, T);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            *(f32x4*)&blk[s0][hp][hr][4 * hq] = o;
+        }
+        TW_FI_STAMP(3);
+        __syncthreads();
+        TW_FI_STAMP(4);
+
+        // ---- phase B2: C — chunk st + NCH into block X, next loads out; S — one pixel per thread from block Y ----
+        if (cth) {
+            if (more && !TW_FI_SKIP(1)) combine_store(st + NCH, dx, dy, q, T);
+            __builtin_amdgcn_sched_barrier(0);
+            TW_FI_STAMP(5);
+            // the next chunk's addresses and the first R0 planes, into the registers the combine has just emptied
+            flow_value(fnext, dx, dy);
+            gather_head(st + NCH + 1, dx, dy, q, T, false);
+            gather_r0(0, q);
+            gather_r0(1, q);
+            gather_r0(2, q);
+            __builtin_amdgcn_sched_barrier(0);
+            TW_FI_STAMP(6);
+        }
+        {
+            const int sy = ys + st * TH + sr;
+            if (sth && sxo < a.w && sy < a.h && !TW_FI_SKIP(8)) {
+                const double g11 = blk[s0][0][sr][sc], g12 = blk[s0][1][sr][sc], g22 = blk[s0][2][sr][sc],
+                             h1 = blk[s0][3][sr][sc], h2 = blk[s0][4][sr][sc];
+                const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
+                const long long o = (long long)sy * a.ld + sxo;
+                fout[o] = (float)((g11 * h2 - g12 * h1) * idet);
+                fout[o + a.fps_out] = (float)((g22 * h1 - g12 * h2) * idet);
+            }
+        }
+        if (cth) {
+            __builtin_amdgcn_sched_barrier(0);
+            gather_r0(3, q);
+            gather_r0(4, q);
+            flow_issue(st + NCH + 2, fnext);
+            ytab_issue(st + NCH + 3);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        TW_FI_STAMP(7);
+        __syncthreads();
+    }
+}
+
 #ifdef TW_VARIANTS
 // -----------------------------------------------------------------------------------------------------
 // tw_blur_solve4q<MH,COLS,HALO,TH,FUSED> (round 4): tw_blur_solve4 with the solve + refresh done BY THE HORIZONTAL ITEM'S

@@ -53,8 +53,8 @@ SYMBOLS = [
     "tw_grid_capacity", "tw_dev_alloc", "tw_dev_free", "tw_dev_upload", "tw_host_alloc", "tw_host_free", "tw_host_register", "tw_host_unregister", "tw_set_option",
     "tw_prof_select", "tw_prof_read",
     "tw_algorithmic_bytes", "tw_algorithmic_bytes_pair", "tw_min_traffic_bytes_pair", "tw_num_levels", "tw_level_chunk", "tw_bench_stage", "tw_stage_pyr_level", "tw_stage_pyr_fused23",
-    "tw_stage_png_unfilter", "tw_stage_polyexp", "tw_stage_update_matrices", "tw_stage_flow_upsample_update", "tw_stage_blur_solve",
-    "tw_debug_graphs", "tw_debug_occupancy", "tw_debug_stamps", "tw_debug_copy_rate",
+    "tw_stage_png_unfilter", "tw_stage_polyexp", "tw_stage_update_matrices", "tw_stage_flow_upsample_update", "tw_stage_blur_solve", "tw_stage_flow_iter",
+    "tw_debug_graphs", "tw_debug_occupancy", "tw_debug_stamps", "tw_debug_stamps_ex", "tw_debug_copy_rate",
 ]
 
 
@@ -145,6 +145,7 @@ def _bind(path):
     L.tw_num_levels.argtypes = [vp, C.c_int, C.c_int]
     L.tw_stage_pyr_level.argtypes = [vp, u8p, C.c_int, C.c_int, C.c_int, fp, ip, ip]
     L.tw_stage_pyr_fused23.argtypes = [vp, u8p, C.c_int, C.c_int, fp, fp]
+    L.tw_stage_flow_iter.argtypes = [vp, fp, fp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, fp]
     L.tw_stage_polyexp.argtypes = [vp, fp, C.c_int, C.c_int, fp]
     L.tw_stage_update_matrices.argtypes = [vp, fp, fp, fp, C.c_int, C.c_int, fp]
     L.tw_stage_flow_upsample_update.argtypes = [vp, fp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, fp, fp]
@@ -427,6 +428,21 @@ class Engine:
         self._check(self._L.tw_stage_flow_upsample_update(self._h, _f(R0), _f(R1), _f(prevflow), pw, ph, w, h,
                                                           _f(flow), _f(M)))
         return flow, M
+
+    def stage_flow_iter(self, R0, R1, flow=None, prev=None):
+        """One whole iteration without M in memory (tw_flow_iter): input flow = `flow` (2, h, w), or the coarser level's
+        flow `prev` (2, ph, pw) upsampled, or zero."""
+        R0 = np.ascontiguousarray(R0, np.float32)
+        R1 = np.ascontiguousarray(R1, np.float32)
+        _, h, w = R0.shape
+        out = np.empty((2, h, w), np.float32)
+        fin = None if flow is None else np.ascontiguousarray(flow, np.float32)
+        pv = None if prev is None else np.ascontiguousarray(prev, np.float32)
+        ph, pw = (pv.shape[1], pv.shape[2]) if pv is not None else (0, 0)
+        null = C.POINTER(C.c_float)()
+        self._check(self._L.tw_stage_flow_iter(self._h, _f(R0), _f(R1), _f(fin) if fin is not None else null,
+                                               _f(pv) if pv is not None else null, pw, ph, w, h, _f(out)))
+        return out
 
     def stage_blur_solve(self, R0, R1, M, update_matrices):
         R0 = np.ascontiguousarray(R0, np.float32)

@@ -32,15 +32,23 @@ def main():
                 if only_lv >= 0 and lv != only_lv:
                     continue
                 n = e.level_chunk(W, H, lv)
-                for flags in ((0, 2) if kc == T.K_BLUR_SOLVE else (0,)):
+                for flags in ((0, 2, 4, 8) if kc == T.K_BLUR_SOLVE else (0,)):
                     if only_flags >= 0 and flags != only_flags:
                         continue
-                    us = e.bench_stage(kc, W, H, lv, n, iters, flags)
+                    try:
+                        us = e.bench_stage(kc, W, H, lv, n, iters, flags)
+                    except T.TwError:
+                        continue  # tw_flow_iter (flags 4 / 8) does not take this level
                     b = e.algorithmic_bytes(kc, lv, W, H) * n
                     if kc == T.K_BLUR_SOLVE:
                         w, h = W >> lv, H >> lv
                         b = (28 + (0 if flags & 2 else 52)) * w * h * n  # as built: the refreshing launch moves 80 B/px
-                    name = T.KERNEL_NAMES[kc] + ("(no refresh)" if flags & 2 else "")
+                        if flags & 4:
+                            b = 56 * w * h * n   # tw_flow_iter: flow 8 + R0 20 + R1 20 in, flow 8 out
+                        if flags & 8:
+                            b = 50 * w * h * n   # ... with the coarser level's flow (2 B/px) instead of this level's
+                    name = T.KERNEL_NAMES[kc] + ("(no refresh)" if flags & 2 else "(M-free)" if flags & 4 else
+                                                 "(M-free+ups)" if flags & 8 else "")
                     print("%-20s %5d %6d %10.1f %10.2f %8.0f" % (name[:20], lv, n, us, us / n, b / us / 1e3 if b else 0))
 
 
