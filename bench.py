@@ -274,8 +274,10 @@ def roofline_obj(name, ms, launches, bytes_total, pairs_per_launch, traffic, chu
                   "passes of an earlier run of this command, not a live counter; measured on launches "
                   "of traffic_pairs_per_launch pairs and scaled to this run's pairs per launch)"),
             "traffic_measured": traffic.get("_provenance"),
-            "bytes_model": "what the kernel as built must move per launch (blur+solve: 80 B/px for a launch "
-                           "fused with the matrix refresh, 28 B/px for the last one; polyexp 24 B/px)",
+            "bytes_model": "what the kernel as built must move per launch (tw_flow_iter, round 5: previous flow 8 + R0 20 + "
+                           "R1 20 in, flow 8 out = 56 B/px, the level's first iteration 48 B/px + the coarser level's "
+                           "flow; with TW_MFREE=0 tw_blur_solve: 80 B/px for a launch fused with the matrix refresh, 28 "
+                           "B/px for the last one; polyexp 24 B/px)",
             "algorithmic_bytes_per_launch": bytes_total / launches,
             "avg_launch_us": round(ms / launches * 1e3, 2), "launches": launches,
             "pairs_per_launch": round(pairs_per_launch, 2), "level_chunk": chunk,
@@ -803,12 +805,22 @@ def main():
             rf = roofline_obj(twflow.KERNEL_NAMES[kc], ms, n, bytes_total, per_pair_launches * pairs_mine / n,
                               traffic, chunk=eng.level_chunk(W, H, 0))
             if rf and kc == twflow.K_BLUR_SOLVE:
-                # the same launches priced on SURVEY 8(d)'s STAGE model instead of the as-built bytes: a refreshing launch
-                # does the work of blur5+solve (28 B/px) AND of updateMatrices (68 B/px); the last one is 28 B/px
-                survey = (2 * (28 + 68) + 28) * float(W * H) * pairs_mine
+                mfree = eng.algorithmic_bytes(twflow.K_UPDATE_MATRICES, 0, W, H) == 0  # level 0 runs tw_flow_iter
+                if mfree:
+                    rf["kernel"] = "tw_flow_iter (one whole iteration, no M in HBM) @level0 (1920x1080)"
+                    # SURVEY 8(d)'s STAGE model of what the three launches of level 0 replace: three updateMatrices (68 B/px,
+                    # the first one included: there is no separate launch for it any more) and three blur5+solve (28 B/px)
+                    survey = 3 * (28 + 68) * float(W * H) * pairs_mine
+                    rf["survey_stage_model_note"] = ("SURVEY 8(d) prices the stages a tw_flow_iter launch replaces at 68 + 28 = 96 "
+                                                     "B/px per launch; `frac` uses the 54 B/px the kernel actually moves (M is "
+                                                     "recomputed in LDS, never stored)")
+                else:
+                    # the same launches priced on SURVEY 8(d)'s STAGE model instead of the as-built bytes: a refreshing launch
+                    # does the work of blur5+solve (28 B/px) AND of updateMatrices (68 B/px); the last one is 28 B/px
+                    survey = (2 * (28 + 68) + 28) * float(W * H) * pairs_mine
+                    rf["survey_stage_model_note"] = ("SURVEY 8(d) prices the stages a fused launch replaces at (2 x 96 + 28) / 3 = "
+                                                     "73.3 B/px per launch; `frac` uses the 62.7 B/px the fused kernels actually move")
                 rf["frac_survey_stage_model"] = round(survey / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
-                rf["survey_stage_model_note"] = ("SURVEY 8(d) prices the stages a fused launch replaces at (2 x 96 + 28) / 3 = "
-                                                 "73.3 B/px per launch; `frac` uses the 62.7 B/px the fused kernels actually move")
             return rf
 
         line = {

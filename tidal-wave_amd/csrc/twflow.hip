@@ -382,7 +382,7 @@ struct tw_engine {
     int scan_fused = 0;    // TW_OPT_SCAN_FUSED_FINAL
     int poly_f32 = 0;      // TW_OPT_POLYEXP_F32 (measurement variant: float accumulators, not bit-exact)
     long long mfree_min_px = 0;  // TW_MFREE_MIN_PX: smallest level (pixels) that takes tw_flow_iter
-    int mfree = 0;         // TW_MFREE=1: levels that qualify run tw_flow_iter (no M in HBM) instead of update + blur launches
+    int mfree = 1;         // TW_MFREE=0: every level runs update + blur launches again (A/B; tw_flow_iter, no M in HBM, is the default)
     int cu_count = 256;
     int pyr_fused = 1;     // TW_PYR_FUSED=0: levels 2 and 3 as two tw_pyr_taps launches again (A/B; tw_pyr_23 is the default)
     int pyr_generic = 0;   // TW_PYR_GENERIC=1: always the generic pyramid kernel, 2: tw_pyr_level_lds for every level (A/B)
@@ -1458,7 +1458,10 @@ tw_status flush_ctx(tw_engine* e, Ctx& c)
                 // level-0 flow is read afterwards, so the last window average + solve runs at the grid points only
                 const bool grid_only = k == 0 && it > 0 && e->scan_fused && c.span == 10 && e->win_m == 15 && !e->box;
                 bool iterated = false;
-                if (e->mfree && !lat && it > 0 && !grid_only && flow_iter_eligible(e, L.w, L.h) &&
+                // (a launch of fewer workgroups than ~3/4 of the CUs — one or two 1080p pairs — leaves the chip to the 224 x 8
+                // tiles of tw_blur_solve4, of which a single pair already makes 1 215)
+                const long long fi_wgs = (long long)((L.w + FI_SC - 31) / (FI_SC - 30)) * std::min(4, std::max(1, L.h / (16 * FI_TH))) * nc;
+                if (e->mfree && !lat && it > 0 && !grid_only && flow_iter_eligible(e, L.w, L.h) && fi_wgs * 4 >= (long long)e->cu_count * 3 &&
                     (e->mfree_min_px <= 0 || (long long)L.w * L.h >= e->mfree_min_px)) {
                     float* buf[2] = {flow_cur, M0};  // iteration i writes buf[(it - 1 - i) & 1]
                     FlowUps ups;
@@ -2408,10 +2411,20 @@ double tw_algorithmic_bytes(const tw_engine* e, int kclass, int level, int width
     level_geometry(width, height, e->p.pyrScale, level, &w, &h, &sg, &ks, &sc);
     const double N = (double)w * h, N0 = (double)width * height;
     const int it = e->p.pyrIterations;
+    // round 5, as built in the batch path: levels that run tw_flow_iter have no FarnebackUpdateMatrices launch and no M
+    // planes (flow 8N + R0 20N + R1 20N in, flow 8N out = 56N per iteration; the first one reads the coarser level's flow,
+    // 8 N_{k+1}, instead of this level's); levels 3 and 2 of an exact-halving pyramid come from one read of the images
+    const bool mfree = e->mfree && it > 0 && flow_iter_eligible(e, w, h) &&
+                       (e->mfree_min_px <= 0 || (long long)w * h >= e->mfree_min_px);
+    const bool fused23 = e->pyr_fused && L >= 3 && e->p.pyrScale == 0.5 && width % 8 == 0 && height % 8 == 0 && width >= 64 &&
+                         height >= 64;
     switch (kclass) {
-        case TW_K_PYR: return 2 * (N0 + 4 * N);
+        case TW_K_PYR:
+            if (fused23 && level == 2) return 2 * (4 * N);  // written by level 3's launch
+            return 2 * (N0 + 4 * N);
         case TW_K_POLYEXP: return 48 * N;  // 2 images x (4 + 20) B/px
         case TW_K_UPDATE_MATRICES: {
+            if (mfree) return 0;
             // R0 20N + R1 20N read, M 20N written; the level's initial flow is read from the coarser level (8 N_{k+1})
             // and is only stored when no iteration follows (the first blur launch recomputes nothing from it: the
             // refresh of iteration 0 uses M, and the flow itself is rewritten by the first solve)
@@ -2428,6 +2441,15 @@ double tw_algorithmic_bytes(const tw_engine* e, int kclass, int level, int width
             // others are fused with the FarnebackUpdateMatrices refresh: M 20N + R0 20N + R1 20N read, M 20N
             // written = 80N — the flow they compute stays in registers and is never stored (counting
             // 28N + 68N charged 16N the kernel does not move).
+            if (mfree) {
+                double first = 48 * N;
+                if (level < L) {
+                    int pw, ph;
+                    level_geometry(width, height, e->p.pyrScale, level + 1, &pw, &ph, &sg, &ks, &sc);
+                    first += 8.0 * pw * ph;
+                }
+                return (first + (it - 1) * 56 * N) / it;
+            }
             return it > 0 ? (28 * N + (it - 1) * 80 * N) / it : 0;
         default: return 0;
     }
