@@ -382,7 +382,8 @@ struct tw_engine {
     int scan_fused = 0;    // TW_OPT_SCAN_FUSED_FINAL
     int poly_f32 = 0;      // TW_OPT_POLYEXP_F32 (measurement variant: float accumulators, not bit-exact)
     long long mfree_min_px = 0;  // TW_MFREE_MIN_PX: smallest level (pixels) that takes tw_flow_iter
-    int mfree = 1;         // TW_MFREE=0: every level runs update + blur launches again (A/B; tw_flow_iter, no M in HBM, is the default)
+    int mfree = 1;         // TW_MFREE=0: every level runs update + blur launches again (A/B; tw_flow_iter, no M in HBM, is the
+                           // default); 2: tw_flow_iter also for launches of a few workgroups (tests, tools/fuzz_parity.py)
     int cu_count = 256;
     int pyr_fused = 1;     // TW_PYR_FUSED=0: levels 2 and 3 as two tw_pyr_taps launches again (A/B; tw_pyr_23 is the default)
     int pyr_generic = 0;   // TW_PYR_GENERIC=1: always the generic pyramid kernel, 2: tw_pyr_level_lds for every level (A/B)
@@ -1461,7 +1462,7 @@ tw_status flush_ctx(tw_engine* e, Ctx& c)
                 // (a launch of fewer workgroups than ~3/4 of the CUs — one or two 1080p pairs — leaves the chip to the 224 x 8
                 // tiles of tw_blur_solve4, of which a single pair already makes 1 215)
                 const long long fi_wgs = (long long)((L.w + FI_SC - 31) / (FI_SC - 30)) * std::min(4, std::max(1, L.h / (16 * FI_TH))) * nc;
-                if (e->mfree && !lat && it > 0 && !grid_only && flow_iter_eligible(e, L.w, L.h) && fi_wgs * 4 >= (long long)e->cu_count * 3 &&
+                if (e->mfree && !lat && it > 0 && !grid_only && flow_iter_eligible(e, L.w, L.h) && (fi_wgs * 4 >= (long long)e->cu_count * 3 || e->mfree == 2) &&
                     (e->mfree_min_px <= 0 || (long long)L.w * L.h >= e->mfree_min_px)) {
                     float* buf[2] = {flow_cur, M0};  // iteration i writes buf[(it - 1 - i) & 1]
                     FlowUps ups;

@@ -2099,6 +2099,54 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     const int sr = sth ? tid / OUT : 0, sc = sth ? tid - sr * OUT : 0;
     const int sxo = bx * OUT + sc;
 
+    // H of one item: (plane hp, row hr, 4-pixel group hq): 36-value window of block bX, four sums into block s0; WITH_LOADS:
+    // the taps of planes 3 and 4 of the thread's phase-C pixel behind the first two pixels (main waves only)
+    auto h_phase = [&](int s0, int bX, auto with_loads_c) {
+        constexpr bool WITH_LOADS = decltype(with_loads_c)::value;
+        float v[4 + 2 * MH + 2];
+        const f32x4* W4 = (const f32x4*)&blk[bX][hp][hr][4 * hq];
+#pragma unroll
+        for (int u = 0; u < (4 + 2 * MH + 2) / 4; u++) {
+            const f32x4 t = W4[u];
+            v[4 * u] = t[0];
+            v[4 * u + 1] = t[1];
+            v[4 * u + 2] = t[2];
+            v[4 * u + 3] = t[3];
+        }
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int li = MH + j;
+            float sum = v[li] * c.k[0];
+#pragma unroll
+            for (int i = 1; i <= MH; i++) sum += c.k[i] * (v[li - i] + v[li + i]);
+            o[j] = sum;
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (WITH_LOADS) {
+                if (j < 2) gather_plane(3 + j, T);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        *(f32x4*)&blk[s0][hp][hr][4 * hq] = o;
+    };
+
+    if (tid >= 960) {
+        // ---- wave 15: no column in V, no pixel in C or S; 40 of the 1 000 H items.  A loop of its own (three barriers per
+        // step, like the others).  Tried here and dropped: an L2 PREFETCH — this otherwise idle wave touching one dword
+        // of every 128-byte line the next chunk's loads will hit (504 lanes, 9 wave-loads per step) — made the launch
+        // 10 % SLOWER (46.7 against 42.3 us per 1080p pair, end to end +1.6 % instead of +7.5 %; gpurun_out/r5s): the
+        // touches take the miss slots the pixels' own loads are short of.
+#pragma unroll 1
+        for (int st = 0; st < nsteps; st++) {
+            const int s0 = st & (NB - 1), bX = (st + NCH) & (NB - 1);
+            __syncthreads();  // (V)
+            if (hth && !TW_FI_SKIP(4)) h_phase(s0, bX, std::false_type());
+            __syncthreads();  // (H)
+            __syncthreads();  // (C, S)
+        }
+        return;
+    }
+
 #pragma unroll 1
     for (int st = 0; st < nsteps; st++) {
         const bool more = st + 1 < nsteps;  // V(st + 1) will run: it needs chunk st + NCH
@@ -2148,33 +2196,9 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
         TW_FI_STAMP(2);
 
         // ---- phase B1: H — (plane, row, 4-pixel group): 36-value window from block X, four sums into block Y ----
-        if (hth && !TW_FI_SKIP(4)) {
-            float v[4 + 2 * MH + 2];
-            const f32x4* W4 = (const f32x4*)&blk[bX][hp][hr][4 * hq];
-#pragma unroll
-            for (int u = 0; u < (4 + 2 * MH + 2) / 4; u++) {
-                const f32x4 t = W4[u];
-                v[4 * u] = t[0];
-                v[4 * u + 1] = t[1];
-                v[4 * u + 2] = t[2];
-                v[4 * u + 3] = t[3];
-            }
-            f32x4 o;
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int li = MH + j;
-                float sum = v[li] * c.k[0];
-#pragma unroll
-                for (int i = 1; i <= MH; i++) sum += c.k[i] * (v[li - i] + v[li + i]);
-                o[j] = sum;
-                __builtin_amdgcn_sched_barrier(0);
-                // (every H thread: the 50 that have no pixel in phase C load from offset 0 of the plane — valid, unused —
-                // rather than make the load conditional: see above)
-                if (j < 2) gather_plane(3 + j, T);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            *(f32x4*)&blk[s0][hp][hr][4 * hq] = o;
-        }
+        // (every H thread of these waves issues the tap loads: the few that have no pixel in phase C load from offset 0 of
+        // the plane — valid, unused — rather than make the load conditional: see above)
+        if (!TW_FI_SKIP(4)) h_phase(s0, bX, std::true_type());
         TW_FI_STAMP(3);
         __syncthreads();
         TW_FI_STAMP(4);

@@ -3,8 +3,12 @@
 2-65, pyrLevels 0-6, iterations 0-5, pyrScale 0.3-0.9, box / Gaussian window, initial-flow flag, polySigma incl. 0),
 four image kinds, random span / threshold — dense flow and vector list of the engine must equal the oracle's bit for
 bit.    tools/fuzz_parity.py [seed]      (3 000 cases or 240 s, whichever comes first)
-Round 2: seeds 2026, 7 and 99 = 6 400 cases, 0 mismatches.  FUZZ_FOCUS=win50: winSize 50 / 51 on 481..1500-pixel-wide images."""
+Round 2: seeds 2026, 7 and 99 = 6 400 cases, 0 mismatches.  FUZZ_FOCUS=win50: winSize 50 / 51 on 481..1500-pixel-wide images.
+FUZZ_FOCUS=mfree (round 5): tw_flow_iter — winSize 30 / 31, Gaussian window, 320..1500-pixel-wide images of 20..560 rows, forced
+for single pairs (TW_MFREE=2, no single-pair stream split) so that every level of >= 320 columns runs it."""
 import sys, os, time
+if os.environ.get("FUZZ_FOCUS","")=="mfree":
+    os.environ["TW_MFREE"]="2"; os.environ["TW_LATENCY_STREAMS"]="0"
 R=os.environ.get("GRAFT_REPO_ROOT","/root/repo")
 sys.path.insert(0,os.path.join(R,"tidal-wave_amd")); sys.path.insert(0,os.path.join(R,"oracle"))
 import numpy as np, twflow as T, oracle as O
@@ -15,9 +19,10 @@ while n < 3000 and time.time()-t0 < 240:
     h,w=int(rng.integers(1,420)),int(rng.integers(1,700))
     focus=os.environ.get("FUZZ_FOCUS","")  # "win50": the 51-tap window kernels on wide levels (round 3's new default)
     if focus=="win50": h,w=int(rng.integers(1,520)),int(rng.integers(481,1500))
-    kw=dict(polyN=int(rng.integers(1,8)), winSize=int(rng.choice([50,51])) if focus=="win50" else int(rng.integers(2,66)), pyrLevels=int(rng.integers(0,7)),
+    if focus=="mfree": h,w=int(rng.integers(20,560)),int(rng.integers(320,1500))
+    kw=dict(polyN=int(rng.integers(1,8)), winSize=int(rng.choice([50,51])) if focus=="win50" else int(rng.choice([30,31])) if focus=="mfree" else int(rng.integers(2,66)), pyrLevels=int(rng.integers(0,7)),
             pyrIterations=int(rng.integers(0,6)), pyrScale=float(rng.choice([0.3,0.45,0.5,0.55,0.6,0.7,0.75,0.8,0.9])),
-            flags=int(rng.choice([0,256,4,260])), polySigma=float(rng.choice([0.0,0.8,1.1,1.5,2.2])))
+            flags=int(rng.choice([256,260])) if focus=="mfree" else int(rng.choice([0,256,4,260])), polySigma=float(rng.choice([0.0,0.8,1.1,1.5,2.2])))
     kind=int(rng.integers(0,4))
     a=rng.integers(0,256,(h,w),dtype=np.uint8)
     if kind==0: a=(a//64*64).astype(np.uint8)
