@@ -2203,20 +2203,9 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
         __syncthreads();
         TW_FI_STAMP(4);
 
-        // ---- phase B2: C — chunk st + NCH into block X, next loads out; S — one pixel per thread from block Y ----
-        if (cth) {
-            if (more && !TW_FI_SKIP(1)) combine_store(st + NCH, dx, dy, q, T);
-            __builtin_amdgcn_sched_barrier(0);
-            TW_FI_STAMP(5);
-            // the next chunk's addresses and the first R0 planes, into the registers the combine has just emptied
-            flow_value(fnext, dx, dy);
-            gather_head(st + NCH + 1, dx, dy, q, T, false);
-            gather_r0(0, q);
-            gather_r0(1, q);
-            gather_r0(2, q);
-            __builtin_amdgcn_sched_barrier(0);
-            TW_FI_STAMP(6);
-        }
+        // ---- phase B2: S — one pixel per thread from block Y; C — chunk st + NCH into block X; the next chunk's head ----
+        // (S first: the taps of planes 3 and 4 went out in the middle of H and get S's time to arrive before the combine
+        // waits for them)
         {
             const int sy = ys + st * TH + sr;
             if (sth && sxo < a.w && sy < a.h && !TW_FI_SKIP(8)) {
@@ -2228,10 +2217,15 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
                 fout[o + a.fps_out] = (float)((g22 * h1 - g12 * h2) * idet);
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
+        TW_FI_STAMP(5);
         if (cth) {
+            if (more && !TW_FI_SKIP(1)) combine_store(st + NCH, dx, dy, q, T);
             __builtin_amdgcn_sched_barrier(0);
-            gather_r0(3, q);
-            gather_r0(4, q);
+            TW_FI_STAMP(6);
+            // the next chunk's addresses, R0 and flow, into the registers the combine has just emptied
+            flow_value(fnext, dx, dy);
+            gather_head(st + NCH + 1, dx, dy, q, T, true);
             flow_issue(st + NCH + 2, fnext);
             ytab_issue(st + NCH + 3);
             __builtin_amdgcn_sched_barrier(0);
