@@ -421,11 +421,24 @@ def config5_4k(twflow, synth, device, batch=16, steps=4, distinct=4):
         by = e.algorithmic_bytes(twflow.K_BLUR_SOLVE, 0, W5, H5) * it * batch * steps
         v = batch * steps / dt
         roof = None
+        # HBM traffic of the 51-tap level-0 launch: two rocprofv3 PMC passes over tools/bench_config5.py (tools/final_profile.sh),
+        # kept in profiles/traffic_cfg5.json with their provenance — a static input here (it used to be null)
+        tr5 = None
+        try:
+            tr5 = json.load(open(os.path.join(ROOT, "profiles", "traffic_cfg5.json")))
+        except Exception:
+            tr5 = None
         if nl:
             gbs = by / (ms * 1e-3) / 1e9
             roof = {"kernel": "tw_blur_solve (51-tap window, winSize 50) @level0 (3840x2160)", "bound": "hbm",
                     "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-                    "traffic": None, "avg_launch_us": round(ms / nl * 1e3, 1), "launches": nl,
+                    "traffic": (round(tr5["bytes_per_launch"] * (it * batch * steps / nl) / tr5["pairs_per_launch"])
+                                if tr5 and tr5.get("pairs_per_launch") else None),
+                    "traffic_source": ("profiles/traffic_cfg5.json (static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over "
+                                       "tools/bench_config5.py, scaled to this run's pairs per launch)" if tr5 else None),
+                    "traffic_measured": tr5.get("_provenance") if tr5 else None,
+                    "traffic_kernel": tr5.get("kernel") if tr5 else None,
+                    "avg_launch_us": round(ms / nl * 1e3, 1), "launches": nl,
                     "pairs_per_launch": round(it * batch * steps / nl, 2),
                     "algorithmic_bytes_per_launch": by / nl,
                     "note": "hipEvent-bracketed level-0 launches of this run; bytes as built (80 B/px fused with the "

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Phase durations of tw_flow_iter from in-kernel s_memtime stamps (variants library, TW_DEBUG_STAMPS=1):
-stamps per step: 0 loop top, 1 end of V, 2 after barrier 1, 3 end of H, 4 after barrier 2, 5 after the combine,
-6 after the next head's loads are issued, 7 end of S (before barrier 3).  Median over workgroups and steps, in cycles."""
+stamps per step: 0 loop top, 1 end of V, 2 after barrier 1, 3 end of H, 4 after barrier 2, 5 end of S, 6 after the
+combine (which first waits for the chunk's loads), 7 after the next chunk's head loads are issued (before barrier 3).
+Median over workgroups and steps, in cycles.  The stamping waves (0 and 9) store each stamp to memory: their own
+sections that wait for memory (the combine, the head issue) read a few hundred cycles long."""
 import ctypes as C
 import os
 import sys
@@ -24,8 +26,8 @@ def main():
         n = L.tw_debug_stamps_ex(e._h, buf, 4096)
         a = np.frombuffer(buf, np.uint64).reshape(32, 2, 8, 8).astype(np.int64)
         print("launch: %.1f us per 64 pairs; %d stamps" % (us, n))
-        names = ["V (+ tap loads)", "wait barrier 1", "H (+ tap loads)", "wait barrier 2", "wait loads + combine",
-                 "issue next head", "S", "wait barrier 3 + loop"]
+        names = ["V (+ tap loads)", "wait barrier 1", "H (+ tap loads)", "wait barrier 2", "S", "wait loads + combine",
+                 "issue next head", "wait barrier 3 + loop"]
         for wv, label in ((0, "wave 0"), (1, "wave 9")):
             s = a[:, wv]
             ok = (s[:, :, 0] > 0) & (s[:, :, 7] > 0)

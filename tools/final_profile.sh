@@ -23,12 +23,37 @@ tools/sq_probe.sh "$out/sq_polyexp" 8 1 0 > "$out/sq_polyexp.txt" 2>&1
 TW_POLYEXP_F32=1 tools/sq_probe.sh "$out/sq_polyexp_f32" 8 1 0 > "$out/sq_polyexp_f32.txt" 2>&1
 TW_POLYEXP_F32=2 tools/sq_probe.sh "$out/sq_polyexp_f32f" 8 1 0 > "$out/sq_polyexp_f32f.txt" 2>&1
 tools/sq_probe.sh "$out/sq_blur_fused" 8 3 0 0 > "$out/sq_blur_fused.txt" 2>&1
-tools/sq_probe.sh "$out/sq_blur_last" 8 3 0 2 > "$out/sq_blur_last.txt" 2>&1
+tools/sq_probe.sh "$out/sq_flow_iter" 8 3 0 4 > "$out/sq_flow_iter.txt" 2>&1
+tools/sq_probe.sh "$out/sq_flow_iter_ups" 8 3 0 8 > "$out/sq_flow_iter_ups.txt" 2>&1
 python3 tools/sq_report.py "$out/sq_polyexp" "tw_polyexp_pk<7, 8, 0>" 265420800 "tw_polyexp_pk<7,8> @ level 0, 64 pairs (128 images of 1920x1080) per launch" packed > "$out/polyexp_sq.md"
-python3 tools/sq_report.py "$out/sq_polyexp_f32" "tw_polyexp_pk<7, 8, 1>" 265420800 "tw_polyexp_pk<7,8,1> (measurement variant TW_OPT_POLYEXP_F32 = 1: float horizontal accumulators, NOT bit-exact) @ level 0, 64 pairs per launch" packed > "$out/polyexp_f32_sq.md"
-python3 tools/sq_report.py "$out/sq_polyexp_f32f" "tw_polyexp_pk<7, 8, 2>" 265420800 "tw_polyexp_pk<7,8,2> (measurement variant TW_OPT_POLYEXP_F32 = 2: float accumulators AND fused multiply-adds, NOT bit-exact) @ level 0, 64 pairs per launch" packed > "$out/polyexp_f32_fused_sq.md"
-python3 tools/sq_report.py "$out/sq_blur_fused" tw_blur_solve4 132710400 "tw_blur_solve4<15,256,16,8> fused with the matrix refresh @ level 0, 64 pairs per launch" > "$out/blur_fused_sq.md"
-python3 tools/sq_report.py "$out/sq_blur_last" tw_blur_solve4 132710400 "tw_blur_solve4<15,256,16,8> last iteration (no refresh) @ level 0, 64 pairs per launch" > "$out/blur_last_sq.md"
+python3 tools/sq_report.py "$out/sq_blur_fused" tw_blur_solve4 132710400 "tw_blur_solve4<15,256,16,8> fused with the matrix refresh @ level 0, 64 pairs per launch (TW_MFREE=0's kernel; what tw_flow_iter replaces)" > "$out/blur_fused_sq.md"
+python3 tools/sq_report.py "$out/sq_flow_iter" "tw_flow_iter<15, 0>" 132710400 "tw_flow_iter<15,0> (one whole iteration, no M in HBM) @ level 0, 64 pairs per launch" > "$out/flow_iter_sq.md"
+python3 tools/sq_report.py "$out/sq_flow_iter_ups" "tw_flow_iter<15, 1>" 132710400 "tw_flow_iter<15,1> (first iteration of a level: flow upsample fused) @ level 0, 64 pairs per launch" > "$out/flow_iter_ups_sq.md"
+python3 tools/fi_stamps.py 4 > "$out/flow_iter_stamps.txt" 2>&1
+# same-lease A/B of the round's two default changes (two runs each, alternating)
+for i in 1 2; do for f in 0 1; do
+  TW_MFREE=$f timeout -k 10 200 python3 bench.py --steps 10 --warmup 2 --no-extras --no-cpu-baseline 2>/dev/null | grep '^{' | tail -1 > "$out/ab_mfree${f}_$i.json"
+done; done
+for i in 1 2; do for f in 0 1; do
+  TW_PYR_FUSED=$f timeout -k 10 200 python3 bench.py --steps 10 --warmup 2 --no-extras --no-cpu-baseline 2>/dev/null | grep '^{' | tail -1 > "$out/ab_pyrfused${f}_$i.json"
+done; done
+python3 - "$out" > "$out/ab_summary.txt" <<'PY'
+import json, sys, glob, os
+for key in ("mfree", "pyrfused"):
+    for f in (0, 1):
+        vals = []
+        for p in sorted(glob.glob(os.path.join(sys.argv[1], "ab_%s%d_*.json" % (key, f)))):
+            try:
+                d = json.loads(open(p).read()); vals.append((d["value"], d["roofline"]["avg_launch_us"] if d.get("roofline") else None))
+            except Exception as e:
+                vals.append(("error", str(e)))
+        print(key, "=", f, vals)
+PY
+# BASELINE config 5 (4K, 51-tap window): HBM traffic of its level-0 window launch
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$out/pmc5_$c" -o run -- python3 tools/bench_config5.py 16 2 > "$out/pmc5_$c.log" 2>&1
+done
+python3 tools/pmc_kernel_traffic.py "$out/pmc5_FETCH_SIZE" "$out/pmc5_WRITE_SIZE" "tw_blur_solve4y<25" 16 "$out/traffic_cfg5.json" "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 tools/bench_config5.py 16 2 (tools/final_profile.sh)" > "$out/traffic_cfg5.log" 2>&1
 python3 tools/clock_watch.py "$out/clock_power.json" -- python3 bench.py --steps 40 --warmup 4 --no-cpu-baseline --no-extras > "$out/clock_power.log" 2>&1
 python3 tools/latency.py 40 > "$out/latency.txt" 2>&1
 python3 tools/polyexp_f32.py > "$out/polyexp_f32.json" 2> "$out/polyexp_f32.err"
