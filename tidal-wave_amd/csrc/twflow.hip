@@ -385,6 +385,7 @@ struct tw_engine {
     int mfree = 1;         // TW_MFREE=0: every level runs update + blur launches again (A/B; tw_flow_iter, no M in HBM, is the
                            // default); 2: tw_flow_iter also for launches of a few workgroups (tests, tools/fuzz_parity.py)
     int cu_count = 256;
+    int blur_cm = 0;       // TW_BLUR_CM=1: tw_blur_solve4y (51-tap window) walks an XCD's tiles column-major (A/B)
     int pyr_fused = 1;     // TW_PYR_FUSED=0: levels 2 and 3 as two tw_pyr_taps launches again (A/B; tw_pyr_23 is the default)
     int pyr_generic = 0;   // TW_PYR_GENERIC=1: always the generic pyramid kernel, 2: tw_pyr_level_lds for every level (A/B)
     int blur_variant = 4;  // 4: tw_blur_solve4 (default); 8: tw_blur_solve8 (packed f32) — TW_BLUR_VARIANT
@@ -1114,6 +1115,7 @@ void launch_blur(tw_engine* e, hipStream_t st, int w, int h, int ld, long long p
     a.store_flow = level < 0 ? 1 : 0;  // level -1: the per-stage test entry point, which returns the flow as well
     a.m = e->win_m;
     a.nomask = e->blur_nomask;
+    a.cm = e->blur_cm;
     a.c = e->wc;
     const int gy = (h + BS_TH - 1) / BS_TH;
     const bool wide = w > 480;  // 224-column tiles; narrow levels use 96-column tiles (less edge waste)
@@ -1977,6 +1979,7 @@ tw_status tw_engine_create(int device, const tw_params* params, int slots, tw_en
     if (const char* ev = getenv("TW_BLUR_VARIANT")) e->blur_variant = atoi(ev);
     if (const char* ev = getenv("TW_PYR_GENERIC")) e->pyr_generic = atoi(ev);
     if (const char* ev = getenv("TW_PYR_FUSED")) e->pyr_fused = atoi(ev) != 0;
+    if (const char* ev = getenv("TW_BLUR_CM")) e->blur_cm = atoi(ev);
     if (const char* ev = getenv("TW_MFREE")) e->mfree = atoi(ev);
     if (const char* ev = getenv("TW_MFREE_MIN_PX")) e->mfree_min_px = atoll(ev);
     {

@@ -97,6 +97,22 @@ __device__ __forceinline__ void xcd_remap(int& bx, int& by, int& bz)
     bz = (int)(t / gy);
 }
 
+// The same bands, walked COLUMN-major (y fastest, then x, then pair): the tiles an XCD runs at any one time are then
+// vertical neighbours.  For the 51-tap window at 4K (66-row register window per 16 output rows, 20 tiles per tile row) a
+// row-major band puts 6.7 MB of other tiles' windows between a tile and the one below it — more than the XCD's 4 MB L2:
+// rocprofv3 FETCH_SIZE + WRITE_SIZE read 1.5 x the 80 B/px the launch has to move (profiles/r05_cfg5_traffic.md).
+__device__ __forceinline__ void xcd_remap_cm(int& bx, int& by, int& bz)
+{
+    const unsigned gx = gridDim.x, gy = gridDim.y, n = gx * gy * gridDim.z;
+    unsigned b = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    const unsigned xcd = b & 7u, q = n >> 3, r = n & 7u;
+    b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+    by = (int)(b % gy);
+    const unsigned t = b / gy;
+    bx = (int)(t % gx);
+    bz = (int)(t / gx);
+}
+
 // borderInterpolate(p, len, BORDER_REFLECT_101)
 __device__ __forceinline__ int reflect101(int p, int len)
 {
@@ -1605,6 +1621,7 @@ struct BlurArgs {
                      // registers and the next launch overwrites it; the engine stores only the last iteration's)
     int m;       // runtime m for the generic kernel
     int nomask;  // A/B switch (TW_BLUR_NOMASK=1): compute the lanes that overhang the image as well
+    int cm;      // tw_blur_solve4y: column-major tile order inside an XCD's band (xcd_remap_cm)
     WinCoef c;
 };
 
@@ -2976,7 +2993,8 @@ __global__ __launch_bounds__(COLS) __attribute__((amdgpu_waves_per_eu(4, 8))) vo
     __shared__ __attribute__((aligned(16))) float sm[5][TH][COLS];
     const int tid = threadIdx.x;
     int bx, by, z;
-    xcd_remap(bx, by, z);
+    if (a.cm) xcd_remap_cm(bx, by, z);
+    else xcd_remap(bx, by, z);
     const int x0 = bx * TW - a.xsh, y00 = by * NR;
     const WinCoef& c = a.c;
     const float* __restrict__ Min = a.Min + (long long)z * 5 * a.ps;

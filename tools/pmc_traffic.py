@@ -55,11 +55,14 @@ def main():
                                      "(tools/final_profile.sh)"}
     # round 5: the level's iterations are tw_flow_iter launches (no M in HBM) unless TW_MFREE=0; the plain iteration
     # (<15, 0>: 2 of the 3 launches of a level) is then the dominant kernel and takes the "tw_blur_solve" slot bench.py reads
-    fi = [r for r in rows if r[0].startswith("tw_flow_iter<15, 0>") and r[1] % (12 * 2 * 1024) == 0]
-    if fi:
+    # (a 1080p pair is 12 strips x 1, 2, 3 or 4 row segments of 1 024 threads: the launch covers the same batch as the
+    # polynomial expansion's level-0 launch, whose pairs the grid arithmetic above has already told)
+    fi = [r for r in rows if r[0].startswith("tw_flow_iter<15, 0>") and r[1] % (12 * 1024) == 0]
+    if fi and out.get("tw_polyexp"):
         big = max(fi, key=lambda r: (r[1], r[2]))
-        out["tw_blur_solve"] = {"bytes_per_launch": round(big[3] + big[4]), "pairs_per_launch": big[1] // (12 * 2 * 1024),
-                                "read_bytes": round(big[3]), "write_bytes": round(big[4]), "kernel": "tw_flow_iter<15, 0>"}
+        out["tw_blur_solve"] = {"bytes_per_launch": round(big[3] + big[4]), "pairs_per_launch": out["tw_polyexp"]["pairs_per_launch"],
+                                "read_bytes": round(big[3]), "write_bytes": round(big[4]), "kernel": "tw_flow_iter<15, 0>",
+                                "grid_threads": big[1]}
     json.dump(out, open(sys.argv[3], "w"), indent=1)
     if len(sys.argv) > 4:
         with open(sys.argv[4], "w") as f:
