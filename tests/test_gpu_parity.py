@@ -497,6 +497,33 @@ def test_scan_fused_final_iteration_option(twflow, oracle, golden):
         assert e.diff(a, b, 10, 1.0)["vector"] == oracle.span_scan(wx, wy, 10, 1.0)
 
 
+def test_scan_fused_final_on_top_of_m_free_iterations(twflow, oracle):
+    """Round 5: with TW_OPT_SCAN_FUSED_FINAL the level-0 iterations but the last run tw_flow_iter, the last flow's M comes
+    from tw_update_matrices<false> and tw_blur_grid evaluates the span-grid points from it — same vectors as the oracle
+    (TW_MFREE=2 forces tw_flow_iter for these small batches; 1, 2, 3 and 4 iterations: one iteration takes the old launches)."""
+    import os
+    import synth
+    os.environ["TW_MFREE"] = "2"
+    os.environ["TW_LATENCY_STREAMS"] = "0"
+    try:
+        pairs = [synth.make_pair(i, 480, 640) for i in range(2)] + [synth.make_pair(1, 230, 330)]
+        for it in (3, 1, 2, 4):
+            p = twflow.default_params(pyrIterations=it)
+            with twflow.Engine(0, p, slots=2) as e:
+                e.set_option(twflow.OPT_SCAN_FUSED_FINAL, 1)
+                for a, b in pairs:
+                    wx, wy = oracle.farneback(a, b, oracle.default_params(pyrIterations=it))
+                    for thr in (2.0, 0.0):
+                        assert e.diff(a, b, 10, thr)["vector"] == oracle.span_scan(wx, wy, 10, thr), (a.shape, it, thr)
+                tk = [e.submit(a, b, 10, 1.0) for a, b in pairs[:2]]
+                for (a, b), t in zip(pairs[:2], tk):
+                    wx, wy = oracle.farneback(a, b, oracle.default_params(pyrIterations=it))
+                    assert e.wait(t)["vector"] == oracle.span_scan(wx, wy, 10, 1.0)
+    finally:
+        del os.environ["TW_MFREE"]
+        del os.environ["TW_LATENCY_STREAMS"]
+
+
 def test_random_medium_shapes_default_and_wide_windows(twflow, oracle):
     """Seeded random sizes between 100 and 700 px (every tile / halo / alignment path of the wide and narrow blur
     kernels, the shifted tile grid, all pyramid kernels) with the default 31-tap window, the 51-tap one and a

@@ -1464,20 +1464,54 @@ tw_status flush_ctx(tw_engine* e, Ctx& c)
                 // (a launch of fewer workgroups than ~3/4 of the CUs — one or two 1080p pairs — leaves the chip to the 224 x 8
                 // tiles of tw_blur_solve4, of which a single pair already makes 1 215)
                 const long long fi_wgs = (long long)((L.w + FI_SC - 31) / (FI_SC - 30)) * std::min(4, std::max(1, L.h / (16 * FI_TH))) * nc;
-                if (e->mfree && !lat && it > 0 && !grid_only && flow_iter_eligible(e, L.w, L.h) && (fi_wgs * 4 >= (long long)e->cu_count * 3 || e->mfree == 2) &&
+                // (with the scan-fused last iteration: it - 1 iterations here, then the M of the last flow from
+                // tw_update_matrices<false> into M1 — tw_blur_grid evaluates the window average + solve at the span-grid
+                // points from it; a single iteration has no flow of this level to start from and takes the old launches)
+                if (e->mfree && !lat && it > (grid_only ? 1 : 0) && flow_iter_eligible(e, L.w, L.h) &&
+                    (fi_wgs * 4 >= (long long)e->cu_count * 3 || e->mfree == 2) &&
                     (e->mfree_min_px <= 0 || (long long)L.w * L.h >= e->mfree_min_px)) {
-                    float* buf[2] = {flow_cur, M0};  // iteration i writes buf[(it - 1 - i) & 1]
+                    const int nfi = grid_only ? it - 1 : it;
+                    float* buf[2] = {flow_cur, M0};  // iteration i writes buf[(nfi - 1 - i) & 1]: the last one the flow buffer
                     FlowUps ups;
                     if (k < pl->levels) {
                         const LevelPlan& Pv = pl->lv[k + 1];
                         ups = FlowUps{flow_prev, Pv.w, Pv.h, Pv.ld, Pv.ps, L.d_uxofs, L.d_uyofs, L.d_ualpha, L.d_ubeta, L.uxmax,
                                       (float)(1. / e->p.pyrScale)};
                     }
-                    for (int i = 0; i < it; i++) {
-                        float* out = buf[(it - 1 - i) & 1];
-                        const float* in = i == 0 ? nullptr : buf[(it - i) & 1];
+                    for (int i = 0; i < nfi; i++) {
+                        float* out = buf[(nfi - 1 - i) & 1];
+                        const float* in = i == 0 ? nullptr : buf[(nfi - i) & 1];
                         launch_flow_iter(e, ls, L.w, L.h, L.ld, L.ps, R, in, L.ps, out, L.ps,
                                          (i == 0 && k < pl->levels) ? &ups : nullptr, nc, k);
+                    }
+                    if (grid_only) {
+                        UpdArgs u;
+                        memset(&u, 0, sizeof(u));
+                        u.R = R;
+                        u.flow = flow_cur;
+                        u.M = M1;
+                        u.w = L.w;
+                        u.h = L.h;
+                        u.ld = L.ld;
+                        u.ps = L.ps;
+                        u.fps = L.ps;
+                        {
+                            ProfScope pscope(e, ls, TW_K_UPDATE_MATRICES, k);
+                            launch_upd_kernel<false>(e, ls, L.w, L.h, nc, u);
+                        }
+                        BlurGridArgs g;
+                        g.Min = M1;
+                        g.w = L.w;
+                        g.h = L.h;
+                        g.ld = L.ld;
+                        g.ps = L.ps;
+                        g.gw = (L.w + c.span - 1) / c.span;
+                        g.gh = (L.h + c.span - 1) / c.span;
+                        g.gzs = (long long)g.gw * g.gh;
+                        g.g = e->d_grid + (size_t)j0 * g.gw * g.gh;
+                        g.c = e->wc;
+                        ProfScope pscope(e, ls, TW_K_BLUR_SOLVE, 0);
+                        hipLaunchKernelGGL((tw_blur_grid<15, 10, 2>), dim3((g.gw + 21) / 22, (g.gh + 1) / 2, nc), dim3(256), 0, ls, g);
                     }
                     iterated = true;
                 }
