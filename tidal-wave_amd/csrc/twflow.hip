@@ -382,6 +382,7 @@ struct tw_engine {
     int scan_fused = 0;    // TW_OPT_SCAN_FUSED_FINAL
     int poly_f32 = 0;      // TW_OPT_POLYEXP_F32 (measurement variant: float accumulators, not bit-exact)
     long long mfree_min_px = 0;  // TW_MFREE_MIN_PX: smallest level (pixels) that takes tw_flow_iter
+    int mfree_min_w = 320;       // TW_MFREE_MIN_W: narrowest level (columns; strips are 160 outputs wide) that takes it
     int mfree = 1;         // TW_MFREE=0: every level runs update + blur launches again (A/B; tw_flow_iter, no M in HBM, is the
                            // default); 2: tw_flow_iter also for launches of a few workgroups (tests, tools/fuzz_parity.py)
     int cu_count = 256;
@@ -1025,7 +1026,7 @@ tw_status launch_polyexp(tw_engine* e, hipStream_t st, int w, int h, int ld, lon
 // 1/pyr_scale of the coarser level's flow computed in place of the load, or zero (both null: the coarsest level).
 bool flow_iter_eligible(const tw_engine* e, int w, int h)
 {
-    return e->win_m == 15 && !e->box && w >= 2 * (FI_SC - 30) && h >= 4 * FI_TH;
+    return e->win_m == 15 && !e->box && w >= e->mfree_min_w && h >= 4 * FI_TH;
 }
 struct FlowUps {  // the coarser level's flow and the resize tables to this level (UpdArgs' upsample fields)
     const float* prev;
@@ -2016,6 +2017,7 @@ tw_status tw_engine_create(int device, const tw_params* params, int slots, tw_en
     if (const char* ev = getenv("TW_BLUR_CM")) e->blur_cm = atoi(ev);
     if (const char* ev = getenv("TW_MFREE")) e->mfree = atoi(ev);
     if (const char* ev = getenv("TW_MFREE_MIN_PX")) e->mfree_min_px = atoll(ev);
+    if (const char* ev = getenv("TW_MFREE_MIN_W")) e->mfree_min_w = std::max(31, atoi(ev));
     {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) e->cu_count = cus;
@@ -3017,7 +3019,7 @@ tw_status tw_stage_flow_iter(tw_engine* e, const float* R0_5, const float* R1_5,
 {
     if (!e || !R0_5 || !R1_5 || !flow_out2 || w < 1 || h < 1 || (flow_in2 && prev2)) return TW_E_BAD_PARAMETER;
     if (!flow_iter_eligible(e, w, h)) {
-        e->err = "tw_stage_flow_iter: winSize 30/31 Gaussian window and a level of at least 320 x 20 pixels";
+        e->err = "tw_stage_flow_iter: winSize 30/31 Gaussian window and a level of at least TW_MFREE_MIN_W (320) x 20 pixels";
         return TW_E_UNSUPPORTED;
     }
     TW_HIP(e, hipSetDevice(e->device));
