@@ -2099,9 +2099,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
         }
         flow_value(fnext, dx, dy);
         gather_head(NCH, dx, dy, q, T, true);
-        flow_issue(NCH + 1, fnext);
-        ytab_issue(NCH + 2);
-        // fnext = input flow of chunk NCH + 1; chunk NCH's head is in flight.  From here on ONE flow
+        // chunk NCH's flow is in dx / dy, its tap addresses are set and its R0 is in flight into q; step 0 loads the flow of
+        // chunk NCH + 1 before its V and turns it into addresses in its phase B2.  From here on ONE flow
         // variable is carried: its arrived value is consumed into dx / dy, then the next load is issued into the same
         // registers — with a second variable copied from it the compiler waited for the load it had just issued,
         // vmcnt(0), before the copy.
@@ -2137,6 +2136,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
             float sum = v[li] * c.k[0];
 #pragma unroll
             for (int i = 1; i <= MH; i++) sum += c.k[i] * (v[li - i] + v[li + i]);
+            // (the compiler sinks the four sums below the tap loads, towards the store that needs them: planes 3 and 4 then
+            // go out at the start of H.  Pinning the sums in place with an opaque use measured 2.6 % slower: gpurun_out/r6b)
             o[j] = sum;
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (WITH_LOADS) {
@@ -2164,26 +2165,31 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
         return;
     }
 
-#pragma unroll 1
-    for (int st = 0; st < nsteps; st++) {
+    // One step.  qc = the R0 coefficients of the chunk this step turns into M (st + NCH; loaded during the PREVIOUS step), qn =
+    // those of the chunk after it, loaded during this step: two register sets that swap roles from step to step — the loop
+    // is unrolled by two so that the swap is a renaming, never a copy (a copy of a register a load is still in flight for
+    // costs an s_waitcnt in place).  With it NO load is left in phase B2 (stamps: seven head loads issued there by all 15
+    // waves at once blocked every wave for ~1 000 cycles): the next chunk's flow before V's first row, its R0 behind V's
+    // rows, this chunk's taps of planes 0-2 behind rows 0-2 and of planes 3-4 behind H's first pixels.
+    auto step = [&](int st, float (&qc)[5], float (&qn)[5]) {
         const bool more = st + 1 < nsteps;  // V(st + 1) will run: it needs chunk st + NCH
         const int s0 = st & (NB - 1), bX = (st + NCH) & (NB - 1);
         TW_FI_STAMP(0);
-        // ---- phase A: V(st) -> block X, with the loads of chunk st + NCH spread through it ----
-        // The memory side of a step (56 B/px + the halo columns: 22.6 us per 1080p pair alone, HBM-bound at 6.1 TB/s) and its
-        // arithmetic (V + H + S: 26.7 us alone) only overlap if requests are QUEUED all through the arithmetic.  Issued in
-        // one piece — at the start of this phase, or right after the previous chunk's combine — the 405 wave-loads of a
-        // step block their waves at the issue (the memory pipe buffers a fraction of them) until most are served, and
-        // the arithmetic phases then run with an idle HBM: 49 us, the plain sum (gpurun_out/r5h).  So: addresses, R0 and the
-        // next chunk's flow before V's first row, one plane of taps after each row.
-        // Schedule of the 17 loads of a pixel, a few at a time: the addresses and three R0 planes right after the previous
-        // chunk's combine in phase B2, the other two and the next chunk's flow behind S, the two 8-byte tap loads of plane r
-        // behind V's row r.  (In-kernel stamps, tools/fi_stamps.py: issued in bursts — 7 or 8 loads by all 15 waves at once
-        // — a burst blocked every wave for ~1 450 cycles at the issue, with the VALUs idle.)
-        // All UNCONDITIONAL for the threads that run V (in the last step of a segment they fetch a chunk nobody needs — row_of
-        // clamps it into the image): a conditional load joins with "no load" in a copy of the loaded register, and the
-        // compiler waits for the load, vmcnt(0), right where it issued it.
+        // ---- phase A: V(st) -> block X, with loads spread through it ----
+        // The memory side of a step (56 B/px + the halo columns: 22.6 us per 1080p pair alone) and its arithmetic (V + H + S:
+        // 26.7 us alone) only overlap if requests are QUEUED all through the arithmetic.  Issued in one piece the 405
+        // wave-loads of a step block their waves at the issue (the memory pipe buffers a fraction of them) until most are
+        // served, and the arithmetic phases then run with an idle memory pipe: 49 us, the plain sum (gpurun_out/r5h).
+        // All loads are UNCONDITIONAL for the threads that run V (in the last steps of a segment they fetch chunks nobody
+        // needs — row_of clamps them into the image): a conditional load joins with "no load" in a copy of the loaded
+        // register, and the compiler waits for the load, vmcnt(0), right where it issued it.
         if (cth) {
+            // the flow of chunk st + NCH + 1 (fnext's previous value — chunk st + NCH — went into dx / dy and the tap addresses
+            // in the previous step's phase B2; this one is consumed in this step's) and that chunk's R0 offset
+            flow_issue(st + NCH + 1, fnext);
+            ytab_issue(st + NCH + 2);
+            gq = (unsigned)(row_of(st + NCH + 1) * a.ld + xc) * 4u;
+            __builtin_amdgcn_sched_barrier(0);
             // The window's chunk j (rows TH*j .. TH*j + TH - 1) sits in block (s0 + j) % NB: the block offsets are wave-uniform
             // (scalar), so a chunk costs one vector add for its address and its TH rows are immediate offsets — no code per
             // rotation.  (An 8-way switch over s0 with the loads AND sums per case compiled without spills, but once global
@@ -2204,7 +2210,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
                 for (int i = 1; i <= MH; i++) sv += (wv[r + MH + i] + wv[r + MH - i]) * c.k[i];
                 vout[r * P] = sv;
                 __builtin_amdgcn_sched_barrier(0);
-                if (r < 3) gather_plane(r, T);  // (the taps of planes 0-2 behind rows 0-2; planes 3, 4 inside H)
+                if (r < 3) gather_plane(r, T);  // (the taps of planes 0-2 of chunk st + NCH behind rows 0-2; planes 3, 4 inside H)
+                gather_r0(r, qn);               // (TH == 5 planes: R0 plane r of chunk st + NCH + 1 behind row r)
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -2220,7 +2227,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
         __syncthreads();
         TW_FI_STAMP(4);
 
-        // ---- phase B2: S — one pixel per thread from block Y; C — chunk st + NCH into block X; the next chunk's head ----
+        // ---- phase B2: S — one pixel per thread from block Y; C — chunk st + NCH into block X; the next chunk's addresses ----
         // (S first: the taps of planes 3 and 4 went out in the middle of H and get S's time to arrive before the combine
         // waits for them)
         {
@@ -2237,18 +2244,26 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
         __builtin_amdgcn_sched_barrier(0);
         TW_FI_STAMP(5);
         if (cth) {
-            if (more && !TW_FI_SKIP(1)) combine_store(st + NCH, dx, dy, q, T);
+            if (more && !TW_FI_SKIP(1)) combine_store(st + NCH, dx, dy, qc, T);
             __builtin_amdgcn_sched_barrier(0);
             TW_FI_STAMP(6);
-            // the next chunk's addresses, R0 and flow, into the registers the combine has just emptied
+            // the next chunk's flow value and tap addresses (no load: its R0 is on its way into qn, its taps follow in V / H)
             flow_value(fnext, dx, dy);
-            gather_head(st + NCH + 1, dx, dy, q, T, true);
-            flow_issue(st + NCH + 2, fnext);
-            ytab_issue(st + NCH + 3);
+            gather_head(st + NCH + 1, dx, dy, qn, T, false);
             __builtin_amdgcn_sched_barrier(0);
         }
         TW_FI_STAMP(7);
         __syncthreads();
+    };
+    float q1[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    {
+        int st = 0;
+#pragma unroll 1
+        for (; st + 1 < nsteps; st += 2) {
+            step(st, q, q1);
+            step(st + 1, q1, q);
+        }
+        if (st < nsteps) step(st, q, q1);
     }
 }
 
