@@ -386,6 +386,7 @@ struct tw_engine {
     int mfree = 1;         // TW_MFREE=0: every level runs update + blur launches again (A/B; tw_flow_iter, no M in HBM, is the
                            // default); 2: tw_flow_iter also for launches of a few workgroups (tests, tools/fuzz_parity.py)
     int cu_count = 256;
+    int pyr23_threads = 512;  // TW_PYR23_THREADS=256: tw_pyr_23 with four instead of eight waves per workgroup (A/B)
     int blur_cm = 0;       // TW_BLUR_CM=1: tw_blur_solve4y (51-tap window) walks an XCD's tiles column-major (A/B)
     int pyr_fused = 1;     // TW_PYR_FUSED=0: levels 2 and 3 as two tw_pyr_taps launches again (A/B; tw_pyr_23 is the default)
     int pyr_generic = 0;   // TW_PYR_GENERIC=1: always the generic pyramid kernel, 2: tw_pyr_level_lds for every level (A/B)
@@ -955,7 +956,9 @@ void launch_pyr23(tw_engine* e, hipStream_t st, const Plan* pl, const uint8_t* c
     memcpy(a.k19, pl->k19, sizeof(a.k19));
     memcpy(a.k9, pl->k9, sizeof(a.k9));
     ProfScope ps(e, st, TW_K_PYR, 3);
-    hipLaunchKernelGGL(tw_pyr_23, dim3((L3.w + P23_T3W - 1) / P23_T3W, (L3.h + P23_T3H - 1) / P23_T3H, nimg), dim3(256), 0, st, a);
+    const dim3 grid((L3.w + P23_T3W - 1) / P23_T3W, (L3.h + P23_T3H - 1) / P23_T3H, nimg);
+    if (e->pyr23_threads == 256) hipLaunchKernelGGL(tw_pyr_23<256>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(tw_pyr_23<512>, grid, dim3(512), 0, st, a);
 }
 
 tw_status launch_polyexp(tw_engine* e, hipStream_t st, int w, int h, int ld, long long ps, const float* I, float* R,
@@ -2015,6 +2018,7 @@ tw_status tw_engine_create(int device, const tw_params* params, int slots, tw_en
     if (const char* ev = getenv("TW_PYR_GENERIC")) e->pyr_generic = atoi(ev);
     if (const char* ev = getenv("TW_PYR_FUSED")) e->pyr_fused = atoi(ev) != 0;
     if (const char* ev = getenv("TW_BLUR_CM")) e->blur_cm = atoi(ev);
+    if (const char* ev = getenv("TW_PYR23_THREADS")) e->pyr23_threads = atoi(ev) == 256 ? 256 : 512;
     if (const char* ev = getenv("TW_MFREE")) e->mfree = atoi(ev);
     if (const char* ev = getenv("TW_MFREE_MIN_PX")) e->mfree_min_px = atoll(ev);
     if (const char* ev = getenv("TW_MFREE_MIN_W")) e->mfree_min_w = std::max(31, atoi(ev));

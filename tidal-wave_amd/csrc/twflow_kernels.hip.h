@@ -624,7 +624,9 @@ struct Pyr23Args {
     float k9[16];   // [0, k0 .. k8, 0, ...]
 };
 
-__global__ __launch_bounds__(256) void tw_pyr_23(Pyr23Args a)
+// NT threads per workgroup (256 or 512: the same tile and LDS, twice the waves to cover the staging latency)
+template <int NT>
+__global__ __launch_bounds__(NT) void tw_pyr_23(Pyr23Args a)
 {
     __shared__ __attribute__((aligned(16))) unsigned tile[P23_R3][P23_PD];
     __shared__ __attribute__((aligned(16))) float rb3[P23_R3][2 * P23_T3W];
@@ -644,11 +646,12 @@ __global__ __launch_bounds__(256) void tw_pyr_23(Pyr23Args a)
         int cc[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) cc[u] = reflect101(col + u, a.w0);
-        constexpr int NR = P23_R3 / 4;  // 13 rows per wave, all loaded before anything is stored
+        constexpr int NWV = NT / 64;
+        constexpr int NR = (P23_R3 + NWV - 1) / NWV;  // 13 (7) rows per wave, all loaded before anything is stored
         unsigned v[NR];
 #pragma unroll
         for (int u = 0; u < NR; u++) {
-            const int Y = reflect101(r0 - 6 + wv + 4 * u, a.h0);
+            const int Y = reflect101(r0 - 6 + min(wv + NWV * u, P23_R3 - 1), a.h0);
             const unsigned ro = (unsigned)(Y * stride);
             if (fast) {
                 v[u] = __builtin_amdgcn_raw_buffer_load_b32(rs, (unsigned)col + ro, 0, 0);
@@ -658,12 +661,13 @@ __global__ __launch_bounds__(256) void tw_pyr_23(Pyr23Args a)
             }
         }
 #pragma unroll
-        for (int u = 0; u < NR; u++) tile[wv + 4 * u][lane] = v[u];
+        for (int u = 0; u < NR; u++)
+            if (wv + NWV * u < P23_R3) tile[wv + NWV * u][lane] = v[u];
     }
     __syncthreads();
 
     // ---- row filter, level 3: columns 8x+3 and 8x+4 of output x, every staged row (1 560 tasks) ----
-    for (int t = tid; t < P23_R3 * P23_T3W; t += 256) {
+    for (int t = tid; t < P23_R3 * P23_T3W; t += NT) {
         const int rr = t / P23_T3W, x = t - rr * P23_T3W;
         // window = 20 bytes from staged byte 8x+2: dwords 2x .. 2x+5, shifted by 2
         const u32x2* D = (const u32x2*)&tile[rr][2 * x];
@@ -691,7 +695,7 @@ __global__ __launch_bounds__(256) void tw_pyr_23(Pyr23Args a)
         *(f32x2*)&rb3[rr][2 * x] = o2;
     }
     // ---- row filter, level 2: columns 4x+1 and 4x+2 of output x, staged rows 3 .. 48 (2 760 tasks) ----
-    for (int t = tid; t < P23_R2 * 2 * P23_T3W; t += 256) {
+    for (int t = tid; t < P23_R2 * 2 * P23_T3W; t += NT) {
         const int rr = t / (2 * P23_T3W), x = t - rr * (2 * P23_T3W);
         // window = 10 bytes from staged byte 4x+5: dwords x+1 .. x+3, shifted by 1 (the bytes past the window weigh 0)
         const unsigned* D = &tile[rr + 3][x + 1];
@@ -745,10 +749,12 @@ __global__ __launch_bounds__(256) void tw_pyr_23(Pyr23Args a)
         const float t0 = c[0].x * 0.5f + c[0].y * 0.5f, t1 = c[1].x * 0.5f + c[1].y * 0.5f;
         if (ox < a.w3 && oy < a.h3) a.dst3[bz * a.zs3 + (long long)oy * a.ld3 + ox] = t0 * 0.5f + t1 * 0.5f;
     }
-    // level 2: 600 outputs; the third round goes to the threads that had no level-3 pixel
-    for (int i = 0; i < 3; i++) {
-        const int t = i < 2 ? tid + 256 * i : tid - 168 + 512;
-        if (i == 2 && tid < 168) break;
+    // level 2: 600 outputs; 256 threads: the third round goes to the threads that had no level-3 pixel; 512 threads: the
+    // second round (88 outputs) likewise
+    constexpr int NRND = NT == 256 ? 3 : 2, LAST0 = NT == 256 ? 168 : 424;
+    for (int i = 0; i < NRND; i++) {
+        const int t = i < NRND - 1 ? tid + NT * i : tid - LAST0 + NT * (NRND - 1);
+        if (i == NRND - 1 && tid < LAST0) break;
         const int y = t / (2 * P23_T3W), x = t - y * (2 * P23_T3W);
         const int ox = bx * (2 * P23_T3W) + x, oy = by * (2 * P23_T3H) + y;
         const float* kc = a.k9 + 1 + 4;
