@@ -227,6 +227,9 @@ tw_status tw_stage_pyr_level(tw_engine* e, const uint8_t* img, int w0, int h0, i
  * (w0/4 x h0/4).  TW_E_UNSUPPORTED when the size has no exact reductions by 4 and 8 (the engine then runs
  * tw_stage_pyr_level's kernels for those levels). */
 tw_status tw_stage_pyr_fused23(tw_engine* e, const uint8_t* img, int w0, int h0, float* I3, float* I2);
+/* Levels 0 and 1 of one image from one read (tw_pyr_k3f; round 5): I0 (w0 x h0) and I1 (w0/2 x h0/2).  TW_E_UNSUPPORTED
+ * when level 1 is not an exact halving with 3-tap smoothing (pyrScale 0.5, even width and height). */
+tw_status tw_stage_pyr_fused01(tw_engine* e, const uint8_t* img, int w0, int h0, float* I0, float* I1);
 /* PNG scanline reconstruction + gray conversion of one image (tw_submit_png8's kernel): `rows` = h rows of
  * 1 + w * channels bytes, channels 1-4; `waves` = 0 (the engine's choice for this width), 1, 4 or 16 waves per image. */
 tw_status tw_stage_png_unfilter(tw_engine* e, const uint8_t* rows, int channels, int w, int h, int waves,

@@ -78,6 +78,23 @@ def test_stage_pyr_fused_levels_2_and_3(engine, oracle, twflow, h, w):
     assert_same(engine.stage_pyr_level(img, 3), I3, "tw_pyr_taps level 3 == fused")
 
 
+@pytest.mark.parametrize("h,w", [(1080, 1920), (480, 640), (482, 646), (64, 64), (66, 130), (270, 2050), (2160, 3840)])
+def test_stage_pyr_fused_levels_0_and_1(engine, oracle, twflow, h, w):
+    """Round 5: levels 0 and 1 (3-tap smoothing, same size / exact 2x2 area reduction) from ONE read of the image
+    (tw_pyr_k3f) — bit-exact against the oracle's per-level pyramid, on whole and ragged 4-pixel groups, rows and columns
+    against the REFLECT101 borders, more than one workgroup per row (2050 columns) and 4K; an odd size is refused."""
+    rng = np.random.default_rng(h * 3 + w)
+    img = rand_img(rng, h, w, smooth=False)
+    img[-h // 6:, -w // 5:] = 255
+    plan = oracle.level_plan(w, h)
+    I0, I1 = engine.stage_pyr_fused01(img)
+    assert_same(I0, oracle.pyr_level(img, plan[0]), "fused pyramid level 0 of %dx%d" % (w, h))
+    assert_same(I1, oracle.pyr_level(img, plan[1]), "fused pyramid level 1 of %dx%d" % (w, h))
+    with pytest.raises(twflow.TwError) as ei:
+        engine.stage_pyr_fused01(img[:, :-1])
+    assert ei.value.code == twflow.TW_E_UNSUPPORTED
+
+
 def test_pyr_fused_refused_for_inexact_sizes_and_batches_agree(twflow, oracle):
     """1366 x 768 has no exact reduction by 8 in x: the stage entry answers TW_E_UNSUPPORTED.  A batch of three 640x480
     pairs runs tw_pyr_23 (the single-pair schedule does not) and must equal the oracle, and the TW_PYR_FUSED=0 engine."""
@@ -495,6 +512,32 @@ def test_scan_fused_final_iteration_option(twflow, oracle, golden):
         a, b = cases[1]
         wx, wy = oracle.farneback(a, b, oracle.default_params(winSize=13))
         assert e.diff(a, b, 10, 1.0)["vector"] == oracle.span_scan(wx, wy, 10, 1.0)
+
+
+def test_pipeline_with_every_round5_fusion_forced(twflow, oracle):
+    """TW_MFREE=2 (tw_flow_iter for every launch of an eligible level): batches of 640x480 and 646x482 pairs then run
+    tw_pyr_k3f (levels 0 + 1 from one read, level 0's images parked in the M1 region), tw_pyr_23 and tw_flow_iter together;
+    flow fields of a batch of one and vectors of a batch of three equal the oracle's."""
+    import os
+    import synth
+    os.environ["TW_MFREE"] = "2"
+    os.environ["TW_LATENCY_STREAMS"] = "0"
+    try:
+        for (h, w) in ((480, 640), (482, 646)):
+            pairs = [synth.make_pair(i, h, w) for i in range(3)]
+            with twflow.Engine(0, twflow.default_params(), slots=4) as e:
+                tk = [e.submit(a, b, 10, 1.0) for a, b in pairs]
+                got = [e.wait(t)["vector"] for t in tk]
+                for (a, b), g in zip(pairs, got):
+                    wx, wy = oracle.farneback(a, b)
+                    assert g == oracle.span_scan(wx, wy, 10, 1.0)
+                gx, gy, _ = e.calculate_internal(*pairs[1])
+                wx, wy = oracle.farneback(*pairs[1])
+                assert_same(gx, wx, "flowx %dx%d" % (w, h))
+                assert_same(gy, wy, "flowy %dx%d" % (w, h))
+    finally:
+        del os.environ["TW_MFREE"]
+        del os.environ["TW_LATENCY_STREAMS"]
 
 
 def test_scan_fused_final_on_top_of_m_free_iterations(twflow, oracle):

@@ -1024,6 +1024,38 @@ tw_status launch_polyexp(tw_engine* e, hipStream_t st, int w, int h, int ld, lon
     return TW_OK;
 }
 
+// levels 1 and 0 of `nimg` images from one read of each image (tw_pyr_k3f): both 3-tap levels of an exact halving
+bool pyr01_fusable(const Plan* pl)
+{
+    return pl->levels >= 1 && pl->lv[0].ksize == 3 && pl->lv[1].ksize == 3 && pl->lv[0].mode == 0 && pl->lv[1].mode == 2 &&
+           pl->w0 == 2 * pl->lv[1].w && pl->h0 == 2 * pl->lv[1].h && pl->w0 >= 16;
+}
+void launch_pyr01(tw_engine* e, hipStream_t st, const Plan* pl, const uint8_t* const* d_srcs, long long stride, float* I1,
+                  float* I0, int nimg)
+{
+    const LevelPlan &L0 = pl->lv[0], &L1 = pl->lv[1];
+    PyrK3fArgs a;
+    a.srcs = d_srcs;
+    a.dst0 = I0;
+    a.dst1 = I1;
+    a.zs0 = L0.ps;
+    a.zs1 = L1.ps;
+    a.stride = stride;
+    a.w0 = pl->w0;
+    a.h0 = pl->h0;
+    a.ld0 = L0.ld;
+    a.w1 = L1.w;
+    a.h1 = L1.h;
+    a.ld1 = L1.ld;
+    a.a0 = L0.h_kern[1];
+    a.a1 = L0.h_kern[0];
+    a.b0 = L1.h_kern[1];
+    a.b1 = L1.h_kern[0];
+    a.aligned4 = (stride % 4 == 0) ? e->img_aligned4 : 0;
+    ProfScope ps(e, st, TW_K_PYR, 1);
+    hipLaunchKernelGGL(tw_pyr_k3f, dim3((L1.w + 255) / 256, (L1.h + 3) / 4, nimg), dim3(256), 0, st, a);
+}
+
 // One whole iteration of the flow update without M in HBM (tw_flow_iter; round 5): flow_out = solve(window average of
 // FarnebackUpdateMatrices(R0, R1, flow_in)).  flow_in: a flow buffer, or (prev != nullptr) the bilinear upsample x
 // 1/pyr_scale of the coarser level's flow computed in place of the load, or zero (both null: the coarsest level).
@@ -1399,6 +1431,16 @@ tw_status flush_ctx(tw_engine* e, Ctx& c)
     }
     // Everything between the batch's start event and the ordered scan, as one function: the single-pair schedule
     // replays it from a captured hipGraph (below), every other batch enqueues it directly.
+    // does level k of a launch of nc pairs run tw_flow_iter?  (a launch of fewer workgroups than ~3/4 of the CUs — one or two
+    // 1080p pairs — leaves the chip to the 224 x 8 tiles of tw_blur_solve4, of which a single pair already makes 1 215)
+    auto level_mfree = [&](int k, int nc) -> bool {
+        const LevelPlan& L = pl->lv[k];
+        const bool grid_only = k == 0 && it > 0 && e->scan_fused && c.span == 10 && e->win_m == 15 && !e->box;
+        const long long fi_wgs = (long long)((L.w + FI_SC - 31) / (FI_SC - 30)) * std::min(4, std::max(1, L.h / (16 * FI_TH))) * nc;
+        return e->mfree && !lat && it > (grid_only ? 1 : 0) && flow_iter_eligible(e, L.w, L.h) &&
+               (fi_wgs * 4 >= (long long)e->cu_count * 3 || e->mfree == 2) &&
+               (e->mfree_min_px <= 0 || (long long)L.w * L.h >= e->mfree_min_px);
+    };
     auto enqueue_levels = [&]() -> tw_status {
     if (lat) {
         TW_HIP(e, hipEventRecord(e->ev_fork, st));  // pointer table + uploads + the previous batch's use of lat_I / lat_R
@@ -1453,9 +1495,16 @@ tw_status flush_ctx(tw_engine* e, Ctx& c)
                     const bool f23 = pl->fused23 && e->pyr_fused && pl->lv[3].chunk >= hi - lo && pl->lv[2].chunk >= hi - lo &&
                                      (size_t)(pl->lv[3].ps + pl->lv[2].ps) * 2 * nc <= ws_lane;
                     float* I2side = I + (size_t)pl->lv[3].ps * 2 * nc;
+                    // levels 1 and 0 likewise (tw_pyr_k3f): level 0's images wait in the M1 region, which nothing else
+                    // touches while levels 1 and 0 both run tw_flow_iter (their iterations ping-pong through M0 only) and
+                    // which is large enough (5 planes per pair against 2 images of one)
+                    const bool f01 = e->pyr_fused && pyr01_fusable(pl) && !e->pyr_generic && pl->lv[1].chunk >= hi - lo &&
+                                     pl->lv[0].chunk >= hi - lo && level_mfree(0, nc) && level_mfree(1, nc);
+                    float* I0side = M1;
                     if (f23 && k == 3) launch_pyr23(e, ls, pl, e->d_ptrs + 2 * j0, stride, I, I2side, 2 * nc);
-                    else if (!(f23 && k == 2)) launch_pyr(e, ls, pl, k, e->d_ptrs + 2 * j0, stride, I, 2 * nc);
-                    const float* Isrc = (f23 && k == 2) ? I2side : I;
+                    else if (f01 && k == 1) launch_pyr01(e, ls, pl, e->d_ptrs + 2 * j0, stride, I, I0side, 2 * nc);
+                    else if (!(f23 && k == 2) && !(f01 && k == 0)) launch_pyr(e, ls, pl, k, e->d_ptrs + 2 * j0, stride, I, 2 * nc);
+                    const float* Isrc = (f23 && k == 2) ? I2side : (f01 && k == 0) ? I0side : I;
                     if ((r = launch_polyexp(e, ls, L.w, L.h, L.ld, L.ps, Isrc, R, 2 * nc, k))) return r;
                 }
                 // M-free iterations (tw_flow_iter; TW_MFREE): the level's iterations read the previous flow and recompute M
@@ -1465,15 +1514,10 @@ tw_status flush_ctx(tw_engine* e, Ctx& c)
                 // level-0 flow is read afterwards, so the last window average + solve runs at the grid points only
                 const bool grid_only = k == 0 && it > 0 && e->scan_fused && c.span == 10 && e->win_m == 15 && !e->box;
                 bool iterated = false;
-                // (a launch of fewer workgroups than ~3/4 of the CUs — one or two 1080p pairs — leaves the chip to the 224 x 8
-                // tiles of tw_blur_solve4, of which a single pair already makes 1 215)
-                const long long fi_wgs = (long long)((L.w + FI_SC - 31) / (FI_SC - 30)) * std::min(4, std::max(1, L.h / (16 * FI_TH))) * nc;
                 // (with the scan-fused last iteration: it - 1 iterations here, then the M of the last flow from
                 // tw_update_matrices<false> into M1 — tw_blur_grid evaluates the window average + solve at the span-grid
                 // points from it; a single iteration has no flow of this level to start from and takes the old launches)
-                if (e->mfree && !lat && it > (grid_only ? 1 : 0) && flow_iter_eligible(e, L.w, L.h) &&
-                    (fi_wgs * 4 >= (long long)e->cu_count * 3 || e->mfree == 2) &&
-                    (e->mfree_min_px <= 0 || (long long)L.w * L.h >= e->mfree_min_px)) {
+                if (level_mfree(k, nc)) {
                     const int nfi = grid_only ? it - 1 : it;
                     float* buf[2] = {flow_cur, M0};  // iteration i writes buf[(nfi - 1 - i) & 1]: the last one the flow buffer
                     FlowUps ups;
@@ -2463,9 +2507,16 @@ double tw_algorithmic_bytes(const tw_engine* e, int kclass, int level, int width
     const bool fused23 = e->pyr_fused && L >= 3 && e->p.pyrScale == 0.5 && width % 8 == 0 && height % 8 == 0 && width >= 64 &&
                          height >= 64;
     switch (kclass) {
-        case TW_K_PYR:
+        case TW_K_PYR: {
             if (fused23 && level == 2) return 2 * (4 * N);  // written by level 3's launch
+            // levels 1 and 0 from one read (tw_pyr_k3f) when both run tw_flow_iter and level 1 is an exact halving
+            int w1 = 0, h1 = 0;
+            if (L >= 1) level_geometry(width, height, e->p.pyrScale, 1, &w1, &h1, &sg, &ks, &sc);
+            const bool fused01 = e->pyr_fused && !e->pyr_generic && L >= 1 && width == 2 * w1 && height == 2 * h1 && width >= 16 &&
+                                 e->mfree && it > 0 && flow_iter_eligible(e, width, height) && flow_iter_eligible(e, w1, h1);
+            if (fused01 && level == 0) return 2 * (4 * N);  // written by level 1's launch
             return 2 * (N0 + 4 * N);
+        }
         case TW_K_POLYEXP: return 48 * N;  // 2 images x (4 + 20) B/px
         case TW_K_UPDATE_MATRICES: {
             if (mfree) return 0;
@@ -2844,6 +2895,37 @@ tw_status tw_stage_pyr_fused23(tw_engine* e, const uint8_t* img, int w0, int h0,
     TW_HIP(e, hipStreamSynchronize(st));
     if ((r = down_planes(e, I3, d_I3, L3.ld, L3.ps, L3.w, L3.h, 1))) return r;
     if ((r = down_planes(e, I2, d_I2, L2.ld, L2.ps, L2.w, L2.h, 1))) return r;
+    return TW_OK;
+}
+
+tw_status tw_stage_pyr_fused01(tw_engine* e, const uint8_t* img, int w0, int h0, float* I0, float* I1)
+{
+    if (!e || !img || !I0 || !I1) return TW_E_BAD_PARAMETER;
+    TW_HIP(e, hipSetDevice(e->device));
+    Plan* pl = nullptr;
+    tw_status r = get_plan(e, w0, h0, &pl);
+    if (r) return r;
+    if (!pyr01_fusable(pl)) {
+        e->err = "tw_stage_pyr_fused01: level 1 of this size / these parameters is not an exact halving with 3-tap smoothing";
+        return TW_E_UNSUPPORTED;
+    }
+    const LevelPlan &L0 = pl->lv[0], &L1 = pl->lv[1];
+    Tmp t;
+    uint8_t* d_img = t.alloc<uint8_t>((size_t)w0 * h0);
+    float* d_I0 = t.alloc<float>((size_t)L0.ps);
+    float* d_I1 = t.alloc<float>((size_t)L1.ps);
+    const uint8_t** d_tab = t.alloc<const uint8_t*>(1);
+    if (!d_img || !d_I0 || !d_I1 || !d_tab) return TW_E_NOMEM;
+    TW_TRY(h2d_sync(e, d_img, img, (size_t)w0 * h0));
+    const uint8_t* hp = d_img;
+    TW_TRY(h2d_sync(e, (void*)d_tab, &hp, sizeof(hp)));
+    hipStream_t st = e->stream;
+    e->img_aligned4 = 1;  // hipMalloc'ed image, dense rows: the kernel itself checks stride % 4
+    launch_pyr01(e, st, pl, d_tab, w0, d_I1, d_I0, 1);
+    TW_HIP(e, hipGetLastError());
+    TW_HIP(e, hipStreamSynchronize(st));
+    if ((r = down_planes(e, I0, d_I0, L0.ld, L0.ps, L0.w, L0.h, 1))) return r;
+    if ((r = down_planes(e, I1, d_I1, L1.ld, L1.ps, L1.w, L1.h, 1))) return r;
     return TW_OK;
 }
 

@@ -952,6 +952,116 @@ __global__ __launch_bounds__(256) void tw_pyr_k3(PyrK3Args a)
     }
 }
 
+// -----------------------------------------------------------------------------------------------------
+// tw_pyr_k3f : levels 0 AND 1 of a ½-pyramid from one read of the u8 image (round 5) — tw_pyr_k3<2>'s thread (8 source
+//   columns x 4 source rows, edge bytes by DPP wave shifts -> 4 level-1 pixels) also produces the 8 x 2 level-0 pixels of
+//   its two centre rows from the same bytes, with level 0's own 3-tap kernel.  12.4 MB instead of 10.4 + 4.1 MB per 1080p
+//   image.  Same float operation order per value as tw_pyr_k3<0> / <2>.
+// -----------------------------------------------------------------------------------------------------
+struct PyrK3fArgs {
+    const uint8_t* const* srcs;
+    float* dst0;  // level-0 images, z-th at dst0 + z*zs0
+    float* dst1;
+    long long zs0, zs1;
+    long long stride;
+    int w0, h0, ld0;   // level 0 = the image's size
+    int w1, h1, ld1;   // level 1 = exactly half of it
+    float a0, a1;      // level 0's centre / side tap
+    float b0, b1;      // level 1's
+    int aligned4;
+};
+
+__global__ __launch_bounds__(256) void tw_pyr_k3f(PyrK3fArgs a)
+{
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // tx = lane: a wave is 64 consecutive 4-pixel groups of level 1
+    const int ox = (blockIdx.x * 64 + tx) * 4;
+    const uint8_t* __restrict__ src = a.srcs[blockIdx.z];
+    const bool in_w = ox < a.w1;  // lanes past the row end stay active for the lane exchange, they only skip memory
+    const int oy = blockIdx.y * 4 + ty;
+    if (oy >= a.h1) return;  // wave-uniform
+    const int sx = 2 * ox;   // first source column of the thread's 8
+    const bool own_ok = a.aligned4 && sx + 7 < a.w0;
+    const bool left_ok = tx > 0 && a.aligned4 && sx - 1 < a.w0;
+    const bool right_ok = tx < 63 && a.aligned4 && sx + 15 < a.w0;
+    unsigned o0[4], o1[4], lb[4], rb[4];
+    const bool need_l = in_w && !left_ok, need_r = in_w && !right_ok, need_own = in_w && !own_ok;
+#pragma unroll
+    for (int rr = 0; rr < 4; rr++) {
+        const int Y = reflect101(2 * oy - 1 + rr, a.h0);
+        const uint8_t* __restrict__ S = src + (long long)Y * a.stride;
+        o0[rr] = o1[rr] = lb[rr] = rb[rr] = 0;
+        if (own_ok) {
+            const u32x2 w2 = *(const u32x2*)(S + sx);
+            o0[rr] = w2.x;
+            o1[rr] = w2.y;
+        }
+        if (need_l) lb[rr] = S[reflect101(sx - 1, a.w0)];
+        if (need_r) rb[rr] = S[reflect101(sx + 8, a.w0)];
+        if (need_own) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                o0[rr] |= (unsigned)S[reflect101(sx + j, a.w0)] << (8 * j);
+                o1[rr] |= (unsigned)S[reflect101(sx + 4 + j, a.w0)] << (8 * j);
+            }
+        }
+    }
+    float rfa[4][8], rfb[4][8];  // row-filtered values with level 0's / level 1's kernel
+#pragma unroll
+    for (int rr = 0; rr < 4; rr++) {
+        const unsigned lw = dpp_from_prev(o1[rr]), rw = dpp_from_next(o0[rr]);
+        float v[10];
+        v[0] = need_l ? (float)lb[rr] : (float)(lw >> 24);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            v[1 + j] = (float)((o0[rr] >> (8 * j)) & 0xffu);
+            v[5 + j] = (float)((o1[rr] >> (8 * j)) & 0xffu);
+        }
+        v[9] = need_r ? (float)rb[rr] : (float)(rw & 0xffu);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            rfa[rr][j] = v[j + 1] * a.a0 + (v[j] + v[j + 2]) * a.a1;
+            rfb[rr][j] = v[j + 1] * a.b0 + (v[j] + v[j + 2]) * a.b1;
+        }
+    }
+    if (!in_w) return;
+    // level 1: column filter at rows 2oy, 2oy+1 and the 2x2 area (tw_pyr_k3<2>)
+    {
+        float o[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const float b00 = (rfb[0][2 * i] + rfb[2][2 * i]) * a.b1 + rfb[1][2 * i] * a.b0;
+            const float b01 = (rfb[0][2 * i + 1] + rfb[2][2 * i + 1]) * a.b1 + rfb[1][2 * i + 1] * a.b0;
+            const float b10 = (rfb[1][2 * i] + rfb[3][2 * i]) * a.b1 + rfb[2][2 * i] * a.b0;
+            const float b11 = (rfb[1][2 * i + 1] + rfb[3][2 * i + 1]) * a.b1 + rfb[2][2 * i + 1] * a.b0;
+            float sum = 0.f;
+            sum += b00 + b01 + b10 + b11;
+            o[i] = sum * 0.25f;
+        }
+        float* d = a.dst1 + blockIdx.z * a.zs1 + (long long)oy * a.ld1 + ox;
+        if (ox + 3 < a.w1) *(f32x4*)d = f32x4{o[0], o[1], o[2], o[3]};
+        else
+            for (int j = 0; j < 4; j++)
+                if (ox + j < a.w1) d[j] = o[j];
+    }
+    // level 0: rows 2oy, 2oy+1, columns sx .. sx+7 (tw_pyr_k3<0>'s column filter)
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const int y0 = 2 * oy + q;
+        if (y0 >= a.h0) break;
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) o[j] = (rfa[q][j] + rfa[q + 2][j]) * a.a1 + rfa[q + 1][j] * a.a0;
+        float* d = a.dst0 + blockIdx.z * a.zs0 + (long long)y0 * a.ld0 + sx;
+        if (sx + 7 < a.w0) {
+            *(f32x4*)d = f32x4{o[0], o[1], o[2], o[3]};
+            *(f32x4*)(d + 4) = f32x4{o[4], o[5], o[6], o[7]};
+        } else {
+            for (int j = 0; j < 8; j++)
+                if (sx + j < a.w0) d[j] = o[j];
+        }
+    }
+}
+
 // =====================================================================================================
 // K5  tw_polyexp<N> : FarnebackPolyExp (optflowgf.cpp) — the roofline-graded kernel, 24 B/px algorithmic.
 //   Tile = 240 columns x 8 rows per 256-thread workgroup (240 + 2x8 halo columns = 256 = one column per

@@ -52,7 +52,7 @@ SYMBOLS = [
     "tw_last_error", "tw_flow_u8", "tw_diff_u8", "tw_submit_u8", "tw_submit_png8", "tw_submit_dev", "tw_flush", "tw_wait",
     "tw_grid_capacity", "tw_dev_alloc", "tw_dev_free", "tw_dev_upload", "tw_host_alloc", "tw_host_free", "tw_host_register", "tw_host_unregister", "tw_set_option",
     "tw_prof_select", "tw_prof_read",
-    "tw_algorithmic_bytes", "tw_algorithmic_bytes_pair", "tw_min_traffic_bytes_pair", "tw_num_levels", "tw_level_chunk", "tw_bench_stage", "tw_stage_pyr_level", "tw_stage_pyr_fused23",
+    "tw_algorithmic_bytes", "tw_algorithmic_bytes_pair", "tw_min_traffic_bytes_pair", "tw_num_levels", "tw_level_chunk", "tw_bench_stage", "tw_stage_pyr_level", "tw_stage_pyr_fused23", "tw_stage_pyr_fused01",
     "tw_stage_png_unfilter", "tw_stage_polyexp", "tw_stage_update_matrices", "tw_stage_flow_upsample_update", "tw_stage_blur_solve", "tw_stage_flow_iter",
     "tw_debug_graphs", "tw_debug_occupancy", "tw_debug_stamps", "tw_debug_stamps_ex", "tw_debug_copy_rate",
 ]
@@ -145,6 +145,7 @@ def _bind(path):
     L.tw_num_levels.argtypes = [vp, C.c_int, C.c_int]
     L.tw_stage_pyr_level.argtypes = [vp, u8p, C.c_int, C.c_int, C.c_int, fp, ip, ip]
     L.tw_stage_pyr_fused23.argtypes = [vp, u8p, C.c_int, C.c_int, fp, fp]
+    L.tw_stage_pyr_fused01.argtypes = [vp, u8p, C.c_int, C.c_int, fp, fp]
     L.tw_stage_flow_iter.argtypes = [vp, fp, fp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, fp]
     L.tw_stage_polyexp.argtypes = [vp, fp, C.c_int, C.c_int, fp]
     L.tw_stage_update_matrices.argtypes = [vp, fp, fp, fp, C.c_int, C.c_int, fp]
@@ -400,6 +401,15 @@ class Engine:
         I2 = np.empty((h0 // 4, w0 // 4), np.float32)
         self._check(self._L.tw_stage_pyr_fused23(self._h, _u8(img), w0, h0, _f(I3), _f(I2)))
         return I3, I2
+
+    def stage_pyr_fused01(self, img):
+        """Levels 0 and 1 from one read of the image (tw_pyr_k3f); TwError(TW_E_UNSUPPORTED) unless level 1 is an exact halving."""
+        img = np.ascontiguousarray(_gray(img))
+        h0, w0 = img.shape
+        I0 = np.empty((h0, w0), np.float32)
+        I1 = np.empty((h0 // 2, w0 // 2), np.float32)
+        self._check(self._L.tw_stage_pyr_fused01(self._h, _u8(img), w0, h0, _f(I0), _f(I1)))
+        return I0, I1
 
     def stage_polyexp(self, I):
         I = np.ascontiguousarray(I, np.float32)
