@@ -196,6 +196,23 @@ def test_stage_flow_iter_without_m(engine, oracle, h, w):
     assert_same(engine.stage_flow_iter(R0, R1), planar(want0), "M-free iteration from zero flow %dx%d" % (w, h))
 
 
+def test_stage_flow_iter_refuses_what_it_cannot_do(twflow, oracle):
+    """Levels narrower than 320 columns or lower than 20 rows, and windows other than winSize 30 / 31, are refused with
+    TW_E_UNSUPPORTED (the engine runs tw_update_matrices + tw_blur_solve* there)."""
+    rng = np.random.default_rng(1)
+    with twflow.Engine(0, twflow.default_params(), slots=1) as e:
+        for (h, w) in ((100, 300), (19, 400)):
+            R0, R1, flow = _rand_fields(rng, h, w)
+            with pytest.raises(twflow.TwError) as ei:
+                e.stage_flow_iter(R0, R1, flow=flow)
+            assert ei.value.code == twflow.TW_E_UNSUPPORTED
+    with twflow.Engine(0, twflow.default_params(winSize=50), slots=1) as e:
+        R0, R1, flow = _rand_fields(rng, 64, 400)
+        with pytest.raises(twflow.TwError) as ei:
+            e.stage_flow_iter(R0, R1, flow=flow)
+        assert ei.value.code == twflow.TW_E_UNSUPPORTED
+
+
 @pytest.mark.parametrize("ph,pw,h,w", [(135, 240, 270, 480), (68, 167, 135, 333), (270, 480, 540, 960)])
 def test_stage_flow_iter_with_fused_upsample(engine, oracle, ph, pw, h, w):
     """The first iteration of a level: input flow = resize(prevFlow, INTER_LINEAR) * 2 computed inside tw_flow_iter<UPS>."""
