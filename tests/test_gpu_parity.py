@@ -557,6 +557,40 @@ def test_pipeline_with_every_round5_fusion_forced(twflow, oracle):
         del os.environ["TW_LATENCY_STREAMS"]
 
 
+def test_single_pair_schedule_of_twin_launches(twflow, oracle):
+    """One pair per batch (BASELINE config[1]): the default schedule carries the finer levels' image-only work inside the
+    coarse-level chain launches (tw_twin_*: two kernel bodies per launch, one stream).  Dense flow and vectors equal the
+    two-stream schedule's (TW_LAT_FUSED=0) at every size, and the oracle's where it is affordable; sizes the fused pyramids
+    do not cover (645 x 483), other iteration counts (1, 2, 5 carriers per level) and other pyramid depths take the same
+    entry point."""
+    import os
+    import synth
+    cases = [((1080, 1920), {}, True), ((720, 1280), {}, False), ((480, 640), {}, True), ((240, 424), {}, True),
+             ((483, 645), {}, False), ((480, 640), {"pyrIterations": 1}, True), ((480, 640), {"pyrIterations": 2}, False),
+             ((480, 640), {"pyrIterations": 5}, False), ((480, 640), {"pyrLevels": 2}, False), ((544, 960), {"pyrLevels": 5}, False)]
+    for (h, w), kw, with_oracle in cases:
+        a, b = synth.make_pair(7, h, w)
+        with twflow.Engine(0, twflow.default_params(**kw), slots=1) as e:
+            gx, gy, _ = e.calculate_internal(a, b)
+            v = e.diff(a, b, 10, 0.5)["vector"]
+            v2 = e.diff(b, a, 10, 0.5)["vector"]   # the same buffers again, the other way round
+        os.environ["TW_LAT_FUSED"] = "0"
+        try:
+            with twflow.Engine(0, twflow.default_params(**kw), slots=1) as e:
+                hx, hy, _ = e.calculate_internal(a, b)
+                assert e.diff(a, b, 10, 0.5)["vector"] == v
+                assert e.diff(b, a, 10, 0.5)["vector"] == v2
+        finally:
+            del os.environ["TW_LAT_FUSED"]
+        assert_same(gx, hx, "flowx %dx%d %r" % (w, h, kw))
+        assert_same(gy, hy, "flowy %dx%d %r" % (w, h, kw))
+        if with_oracle:
+            wx, wy = oracle.farneback(a, b, oracle.default_params(**kw))
+            assert_same(gx, wx, "flowx vs oracle %dx%d %r" % (w, h, kw))
+            assert_same(gy, wy, "flowy vs oracle %dx%d %r" % (w, h, kw))
+            assert v == oracle.span_scan(wx, wy, 10, 0.5)
+
+
 def test_scan_fused_final_on_top_of_m_free_iterations(twflow, oracle):
     """Round 5: with TW_OPT_SCAN_FUSED_FINAL the level-0 iterations but the last run tw_flow_iter, the last flow's M comes
     from tw_update_matrices<false> and tw_blur_grid evaluates the span-grid points from it — same vectors as the oracle
@@ -952,6 +986,7 @@ def test_debug_stamps_buffer_survives_the_latency_workspace(twflow, oracle, monk
     import ctypes as C
     import synth
     monkeypatch.setenv("TW_DEBUG_STAMPS", "1")
+    monkeypatch.setenv("TW_LAT_FUSED", "0")   # the two-stream schedule: tw_pyr_taps is the kernel that writes the stamps
     a, b = synth.make_pair(1, 1080, 1920)
     wx, wy = oracle.farneback(a, b)
     with twflow.Engine(0, twflow.default_params(), slots=1) as e:

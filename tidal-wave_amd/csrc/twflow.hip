@@ -413,6 +413,7 @@ struct tw_engine {
     size_t lat_cap = 0;  // floats in lat_I (lat_R holds 5x)
     std::vector<hipEvent_t> lat_ev;
     int lat_s2_max = 1000;  // TW_LAT_S2_LEVELS: finest..this level's image-only work goes to the second stream
+    int lat_fused = 1;  // TW_LAT_FUSED=0: the two-stream single-pair schedule of rounds 2-4 instead of the twin launches (A/B)
     int lat_graph = 0;  // TW_LAT_GRAPH=1: replay the single-pair schedule from a captured hipGraph (measured SLOWER on
                         // ROCm 7.2: 0.55 ms vs 0.37 ms — profiles/r03_latency.md — so it is opt-in, kept for re-measuring)
     std::map<GraphKey, hipGraphExec_t> lat_graphs;  // captured single-pair schedules (dropped whenever a buffer moves)
@@ -842,9 +843,37 @@ struct ProfScope {
     }
 };
 
+// A side job of the single-pair schedule: image-only work (a band of a level's polynomial expansion, or the level 0 / 1
+// images) that rides in the same launch as a kernel of the dependent flow chain (the twin kernels of twflow_kernels.hip.h).
+// A launcher that has a twin for its kernel sets *used; the caller launches the job by itself otherwise.
+struct SideJob {
+    int kind = 0;        // 1: polynomial-expansion band (tw_polyexp_pk<7, 8, 0>), 2: tw_pyr_k3f
+    int need_level = 0;  // the finest level whose flow chain reads what the job writes
+    PolyArgs pa;
+    PyrK3fArgs ka;
+    VGrid g;             // the job's workgroups
+    unsigned n() const { return g.gx * g.gy * g.gz; }
+};
+TwinGrid make_twin(const dim3& ga, const SideJob& s)
+{
+    TwinGrid t;
+    t.a = VGrid{ga.x, ga.y, ga.z, 0u, 0u};
+    t.b = s.g;
+    t.nA = ga.x * ga.y * ga.z;
+    t.nA8 = (t.nA + 7u) & ~7u;
+    return t;
+}
+void launch_side_alone(tw_engine* e, hipStream_t st, const SideJob& s)
+{
+    (void)e;
+    if (s.kind == 1) hipLaunchKernelGGL(tw_polyexp_band, dim3(s.n()), dim3(256), 0, st, s.pa, s.g);
+    else if (s.kind == 2) hipLaunchKernelGGL(tw_pyr_k3f, dim3(s.g.gx, s.g.gy, s.g.gz), dim3(256), 0, st, s.ka);
+}
+
 // tw_update_matrices<UPSAMPLE, NY>: NY pixels of a column per lane (TW_UPD_NY, default 2)
 template <bool UP>
-void launch_upd_kernel(tw_engine* e, hipStream_t st, int w, int h, int npairs, const UpdArgs& a)
+void launch_upd_kernel(tw_engine* e, hipStream_t st, int w, int h, int npairs, const UpdArgs& a, const SideJob* side = nullptr,
+                       bool* side_used = nullptr)
 {
 #ifdef TW_VARIANTS
     if (e->upd_ny == 1) {
@@ -852,7 +881,14 @@ void launch_upd_kernel(tw_engine* e, hipStream_t st, int w, int h, int npairs, c
         return;
     }
 #endif
-    hipLaunchKernelGGL((tw_update_matrices<UP, 2>), dim3((w + 63) / 64, (h + 7) / 8, npairs), dim3(256), 0, st, a);
+    const dim3 grid((w + 63) / 64, (h + 7) / 8, npairs);
+    if (side && side_used && side->kind == 1) {
+        const TwinGrid t = make_twin(grid, *side);
+        hipLaunchKernelGGL(tw_twin_upd_poly<UP>, dim3(t.nA8 + side->n()), dim3(256), 0, st, a, side->pa, t);
+        *side_used = true;
+        return;
+    }
+    hipLaunchKernelGGL((tw_update_matrices<UP, 2>), grid, dim3(256), 0, st, a);
 }
 
 // ---- kernel launch helpers (nz = images or pairs in this launch) -------------------------------------
@@ -962,7 +998,7 @@ void launch_pyr23(tw_engine* e, hipStream_t st, const Plan* pl, const uint8_t* c
 }
 
 tw_status launch_polyexp(tw_engine* e, hipStream_t st, int w, int h, int ld, long long ps, const float* I, float* R,
-                         int nimg, int level)
+                         int nimg, int level, const SideJob* side = nullptr, bool* side_used = nullptr)
 {
     PolyArgs a;
     a.src = I;
@@ -1016,6 +1052,12 @@ tw_status launch_polyexp(tw_engine* e, hipStream_t st, int w, int h, int ld, lon
 #define TW_PK_CASE(n)                                                                        \
     case n: hipLaunchKernelGGL((tw_polyexp_pk<n, 8, 0>), grid, dim3(256), 0, st, a); break;
 #endif
+    if (side && side_used && side->kind == 2 && e->p.polyN == 7 && e->poly_variant == 1) {
+        const TwinGrid t = make_twin(grid, *side);
+        hipLaunchKernelGGL(tw_twin_poly_k3f, dim3(t.nA8 + side->n()), dim3(256), 0, st, a, side->ka, t);
+        *side_used = true;
+        return TW_OK;
+    }
     switch (e->p.polyN) {
         TW_PK_CASE(1) TW_PK_CASE(2) TW_PK_CASE(3) TW_PK_CASE(4) TW_PK_CASE(5) TW_PK_CASE(6) TW_PK_CASE(7)
         default: e->err = "polyN must be 1..7"; return TW_E_UNSUPPORTED;
@@ -1133,7 +1175,8 @@ void launch_flow_iter(tw_engine* e, hipStream_t st, int w, int h, int ld, long l
 }
 
 void launch_blur(tw_engine* e, hipStream_t st, int w, int h, int ld, long long ps, const float* Min, float* Mout,
-                 float* flow, const float* R, int update, int level, int npairs, double* Vbox = nullptr)
+                 float* flow, const float* R, int update, int level, int npairs, double* Vbox = nullptr,
+                 const SideJob* side = nullptr, bool* side_used = nullptr)
 {
     BlurArgs a;
     a.Min = Min;
@@ -1228,6 +1271,11 @@ void launch_blur(tw_engine* e, hipStream_t st, int w, int h, int ld, long long p
             else if (small == 3) hipLaunchKernelGGL((tw_blur_solve4<15, 64, 16, 4, true>), grid, dim3(64), 0, st, a);
             else if (small == 5) hipLaunchKernelGGL((tw_blur_solve_pp<15, 128, 16, 8>), grid, dim3(640), 0, st, a);
 #endif
+            else if (side && side_used && side->kind == 1) {
+                const TwinGrid t = make_twin(grid, *side);
+                hipLaunchKernelGGL(tw_twin_pp_poly, dim3(t.nA8 + side->n()), dim3(320), 0, st, a, side->pa, t);
+                *side_used = true;
+            }
             else hipLaunchKernelGGL((tw_blur_solve_pp<15, 64, 16, 8>), grid, dim3(320), 0, st, a);
             return;
         }
@@ -1306,7 +1354,7 @@ void launch_blur(tw_engine* e, hipStream_t st, int w, int h, int ld, long long p
 }
 
 void launch_update(tw_engine* e, hipStream_t st, const Plan* pl, int k, const float* R, float* flow,
-                   const float* prev, float* M, int npairs)
+                   const float* prev, float* M, int npairs, const SideJob* side = nullptr, bool* side_used = nullptr)
 {
     const LevelPlan& L = pl->lv[k];
     UpdArgs a;
@@ -1334,10 +1382,10 @@ void launch_update(tw_engine* e, hipStream_t st, const Plan* pl, int k, const fl
         a.beta = L.d_ubeta;
         a.xmax = L.uxmax;
         a.scale = (float)(1. / e->p.pyrScale);
-        launch_upd_kernel<true>(e, st, L.w, L.h, npairs, a);
+        launch_upd_kernel<true>(e, st, L.w, L.h, npairs, a, side, side_used);
     } else {
         a.zero_flow = 1;
-        launch_upd_kernel<false>(e, st, L.w, L.h, npairs, a);
+        launch_upd_kernel<false>(e, st, L.w, L.h, npairs, a, side, side_used);
     }
 }
 
@@ -1421,6 +1469,16 @@ tw_status flush_ctx(tw_engine* e, Ctx& c)
     // (only worth its cross-stream hand-offs when the image-only work is tens of microseconds: >= 0.1 Mpixel)
     const bool lat = n == 1 && nlanes == 1 && e->lat_streams && e->lat_I && pl->levels >= 1 &&
                      (long long)c.w * c.h >= e->lat_min_px;
+    bool prof_on = false;
+    for (int i = 0; i < TW_K_COUNT; i++) prof_on = prof_on || e->prof_level[i] != -2;
+    // ... or, for the default parameters at sizes whose pyramid halves exactly (1080p: BASELINE config 2), ONE stream of twin
+    // launches: every coarse-level chain kernel carries a piece of the finer levels' image-only work in its own launch
+    // (twflow_kernels.hip.h: tw_twin_*) — no cross-queue hand-off anywhere in the pair
+    const bool lat2 = lat && e->lat_fused && !e->lat_graph && !prof_on && pl->levels == 3 && pl->fused23 && e->pyr_fused &&
+                      pyr01_fusable(pl) && !e->pyr_generic && e->p.polyN == 7 && !e->poly_f32 && e->poly_variant == 1 &&
+                      e->upd_ny == 2 && e->win_m == 15 && !e->box && it >= 1;
+    std::vector<SideJob> sideq;
+    size_t side_next = 0;
     std::vector<size_t> lat_off(pl->lv.size(), 0);
     if (lat) {
         size_t off = 0;
@@ -1442,7 +1500,7 @@ tw_status flush_ctx(tw_engine* e, Ctx& c)
                (e->mfree_min_px <= 0 || (long long)L.w * L.h >= e->mfree_min_px);
     };
     auto enqueue_levels = [&]() -> tw_status {
-    if (lat) {
+    if (lat && !lat2) {
         TW_HIP(e, hipEventRecord(e->ev_fork, st));  // pointer table + uploads + the previous batch's use of lat_I / lat_R
         TW_HIP(e, hipStreamWaitEvent(e->stream2, e->ev_fork, 0));
     }
@@ -1460,7 +1518,81 @@ tw_status flush_ctx(tw_engine* e, Ctx& c)
         if (second) TW_HIP(e, hipEventRecord(e->lat_ev[k], e->stream2));
         return TW_OK;
     };
-    if (lat) {
+    // the side jobs of the twin schedule, in the order the chain needs their results
+    auto side_poly = [&](int k, int z0, int nz, int y0, int ny) {
+        const LevelPlan& L = pl->lv[k];
+        SideJob j;
+        j.kind = 1;
+        j.need_level = k;
+        j.pa.src = e->lat_I + lat_off[k];
+        j.pa.dst = e->lat_R + 5 * lat_off[k];
+        j.pa.w = L.w;
+        j.pa.h = L.h;
+        j.pa.ld = L.ld;
+        j.pa.ps = L.ps;
+        j.pa.c = e->pc;
+        j.g = VGrid{(unsigned)((L.w + PE_TW - 1) / PE_TW), (unsigned)ny, (unsigned)nz, (unsigned)y0, (unsigned)z0};
+        sideq.push_back(j);
+    };
+    // the next side job, for the launcher of a chain kernel; side_done launches it by itself if the launcher had no twin
+    // measurement: TW_LAT_ALONE=1 every side job as its own launch; =2 also the chain kernels through their twins (empty side)
+    static const int side_alone = getenv("TW_LAT_ALONE") ? atoi(getenv("TW_LAT_ALONE")) : 0;
+    static SideJob empty_side;
+    empty_side.kind = 1;
+    empty_side.g = VGrid{0u, 0u, 0u, 0u, 0u};
+    auto side_peek = [&]() -> const SideJob* {
+        if (side_next >= sideq.size()) return nullptr;
+        return side_alone == 2 ? &empty_side : side_alone ? nullptr : &sideq[side_next];
+    };
+    auto side_done = [&](bool used) {
+        if (side_next >= sideq.size()) return;
+        if (!used || side_alone) launch_side_alone(e, st, sideq[side_next]);
+        side_next++;
+    };
+    if (lat2) {
+        sideq.clear();
+        side_next = 0;
+        launch_pyr23(e, st, pl, e->d_ptrs, stride, e->lat_I + lat_off[3], e->lat_I + lat_off[2], 2);
+        {   // the coarsest level's expansion carries the level 0 / 1 images
+            const LevelPlan &L0 = pl->lv[0], &L1 = pl->lv[1], &L3 = pl->lv[3];
+            SideJob j;
+            j.kind = 2;
+            j.need_level = 1;
+            PyrK3fArgs& a = j.ka;
+            a.srcs = e->d_ptrs;
+            a.dst0 = e->lat_I + lat_off[0];
+            a.dst1 = e->lat_I + lat_off[1];
+            a.zs0 = L0.ps;
+            a.zs1 = L1.ps;
+            a.stride = stride;
+            a.w0 = pl->w0;
+            a.h0 = pl->h0;
+            a.ld0 = L0.ld;
+            a.w1 = L1.w;
+            a.h1 = L1.h;
+            a.ld1 = L1.ld;
+            a.a0 = L0.h_kern[1];
+            a.a1 = L0.h_kern[0];
+            a.b0 = L1.h_kern[1];
+            a.b1 = L1.h_kern[0];
+            a.aligned4 = (stride % 4 == 0) ? e->img_aligned4 : 0;
+            j.g = VGrid{(unsigned)((L1.w + 255) / 256), (unsigned)((L1.h + 3) / 4), 2u, 0u, 0u};
+            bool used = false;
+            if ((r = launch_polyexp(e, st, L3.w, L3.h, L3.ld, L3.ps, e->lat_I + lat_off[3], e->lat_R + 5 * lat_off[3], 2, 3, &j, &used)))
+                return r;
+            if (!used) launch_side_alone(e, st, j);
+        }
+        // carriers: the update + `it` window launches of levels 3 and 2, and level 1's update
+        const int carriers = 2 * (it + 1) + 1;
+        const int gy2 = (pl->lv[2].h + PE_TH - 1) / PE_TH, gy1 = (pl->lv[1].h + PE_TH - 1) / PE_TH, gy0 = (pl->lv[0].h + PE_TH - 1) / PE_TH;
+        side_poly(2, 0, 2, 0, gy2);
+        side_poly(1, 0, 1, 0, gy1);
+        side_poly(1, 1, 1, 0, gy1);
+        const int nb = std::min(8, std::max(1, (carriers - 3) / 2));  // bands per level-0 image
+        const int rows = (gy0 + nb - 1) / nb;
+        for (int z = 0; z < 2; z++)
+            for (int y0 = 0; y0 < gy0; y0 += rows) side_poly(0, z, 1, y0, std::min(rows, gy0 - y0));
+    } else if (lat) {
         if ((r = lat_images(pl->levels))) return r;
         if (pl->levels >= 1 && (r = lat_images(pl->levels - 1))) return r;
     }
@@ -1483,7 +1615,11 @@ tw_status flush_ctx(tw_engine* e, Ctx& c)
                 float* flow_cur = e->flow[k] + (k == 0 ? (size_t)lane * L.chunk * 2 * L.ps : (size_t)j0 * 2 * L.ps);
                 const float* flow_prev =
                     k < pl->levels ? e->flow[k + 1] + (size_t)j0 * 2 * pl->lv[k + 1].ps : nullptr;
-                if (lat) {
+                if (lat2) {
+                    R = e->lat_R + 5 * lat_off[k];
+                    // whatever this level reads and no chain kernel was left to carry goes out by itself
+                    while (side_next < sideq.size() && sideq[side_next].need_level >= k) side_done(false);
+                } else if (lat) {
                     R = e->lat_R + 5 * lat_off[k];
                     if (k < pl->levels && k <= e->lat_s2_max) TW_HIP(e, hipStreamWaitEvent(ls, e->lat_ev[k], 0));
                 } else {
@@ -1563,7 +1699,15 @@ tw_status flush_ctx(tw_engine* e, Ctx& c)
                     }
                     iterated = true;
                 }
-                if (!iterated) launch_update(e, ls, pl, k, R, flow_cur, flow_prev, M0, nc);
+                if (!iterated) {
+                    if (lat2 && k >= 1) {
+                        bool used = false;
+                        launch_update(e, ls, pl, k, R, flow_cur, flow_prev, M0, nc, side_peek(), &used);
+                        side_done(used);
+                    } else {
+                        launch_update(e, ls, pl, k, R, flow_cur, flow_prev, M0, nc);
+                    }
+                }
                 for (int i = 0; i < it && !iterated; i++) {
                     if (grid_only && i == it - 1) {
                         BlurGridArgs g;
@@ -1581,11 +1725,19 @@ tw_status flush_ctx(tw_engine* e, Ctx& c)
                         hipLaunchKernelGGL((tw_blur_grid<15, 10, 2>), dim3((g.gw + 21) / 22, (g.gh + 1) / 2, nc), dim3(256), 0, ls, g);
                         break;
                     }
+                    if (lat2 && k >= 2) {
+                        bool used = false;
+                        launch_blur(e, ls, L.w, L.h, L.ld, L.ps, (i & 1) ? M1 : M0, (i & 1) ? M0 : M1, flow_cur, R, i < it - 1, k, nc,
+                                    nullptr, side_peek(), &used);
+                        side_done(used);
+                        continue;
+                    }
                     launch_blur(e, ls, L.w, L.h, L.ld, L.ps, (i & 1) ? M1 : M0, (i & 1) ? M0 : M1, flow_cur, R,
                                 i < it - 1, k, nc, e->Vd ? e->Vd + ws_lane / 2 * 5 * lane : nullptr);
                 }
-                if (k == 0 && c.span > 0 && !grid_only) {
-                    // grid samples of this chunk -> dense per-pair buffer (the ordered scan runs once per batch)
+                if (k == 0 && c.span > 0 && !grid_only && !lat) {
+                    // grid samples of this chunk -> dense per-pair buffer (the ordered scan runs once per batch;
+                    // a single pair's scan reads the flow planes itself)
                     GatherArgs g;
                     g.flow = flow_cur;
                     g.fzs = 2 * L.ps;
@@ -1599,7 +1751,7 @@ tw_status flush_ctx(tw_engine* e, Ctx& c)
                     hipLaunchKernelGGL(tw_span_gather, dim3((g.gw + 63) / 64, (g.gh + 3) / 4, nc), dim3(256), 0, ls, g);
                 }
                 // the image-only work two levels below goes out once this level's chain is enqueued
-                if (lat && k >= 2 && (r = lat_images(k - 2))) return r;
+                if (lat && !lat2 && k >= 2 && (r = lat_images(k - 2))) return r;
             }
         }
     }
@@ -1617,8 +1769,6 @@ tw_status flush_ctx(tw_engine* e, Ctx& c)
     // (the direct enqueue takes 110 us of host time for 375 us of GPU time, TW_DEBUG_HOSTTIME), and the replayed graph
     // is slower (0.55 ms: kernels of the forked branch stretch to ~40 us quanta behind cross-queue signals), so the
     // direct path is the default and the graph an opt-in A/B switch (profiles/r03_latency.md).
-    bool prof_on = false;
-    for (int i = 0; i < TW_K_COUNT; i++) prof_on = prof_on || e->prof_level[i] != -2;
     bool launched_graph = false;
     if (lat && e->lat_graph && !prof_on) {
         const GraphKey key{c.w, c.h, c.span, stride, e->img_aligned4, e->scan_fused, e->poly_f32};
@@ -1670,8 +1820,13 @@ tw_status flush_ctx(tw_engine* e, Ctx& c)
         a.count = e->d_count;
         a.rec_zs = (long long)a.gw * a.gh;
         a.rec = c.d_rec;
+        a.flow = e->flow[0];
+        a.fps = L.ps;
+        a.ld = L.ld;
+        const bool grid_only = e->p.pyrIterations > 0 && e->scan_fused && c.span == 10 && e->win_m == 15 && !e->box;
         ProfScope pscope(e, st, TW_K_SCAN, 0);
-        hipLaunchKernelGGL(tw_span_scan, dim3(n), dim3(1024), 0, st, a);
+        if (lat && !grid_only) hipLaunchKernelGGL(tw_span_scan<true>, dim3(n), dim3(1024), 0, st, a);
+        else hipLaunchKernelGGL(tw_span_scan<false>, dim3(n), dim3(1024), 0, st, a);
     }
     TW_HIP(e, hipEventRecord(c.ev_stop, st));
     if (c.span > 0) {
@@ -2109,6 +2264,7 @@ tw_status tw_engine_create(int device, const tw_params* params, int slots, tw_en
     if (const char* ev = getenv("TW_LATENCY_STREAMS")) e->lat_streams = atoi(ev) ? 1 : 0;
     if (const char* ev = getenv("TW_LATENCY_MIN_PX")) e->lat_min_px = atoll(ev);
     if (const char* ev = getenv("TW_LAT_GRAPH")) e->lat_graph = atoi(ev) ? 1 : 0;
+    if (const char* ev = getenv("TW_LAT_FUSED")) e->lat_fused = atoi(ev) ? 1 : 0;
     if (const char* ev = getenv("TW_LAT_S2_LEVELS")) e->lat_s2_max = atoi(ev);
     // the main stream carries the dependent flow chain: highest priority, so that its small launches are not queued
     // behind the second stream's image-only work
@@ -2815,7 +2971,8 @@ extern "C" tw_status tw_bench_stage(tw_engine* e, int kclass, int width, int hei
                 ScanArgs a;
                 a.g = grid; a.span = span; a.gw = g.gw; a.gh = g.gh; a.thr2 = 4.0; a.count = cnt;
                 a.rec = rec; a.rec_zs = (long long)a.gw * a.gh;
-                hipLaunchKernelGGL(tw_span_scan, dim3(npairs), dim3(1024), 0, st, a);
+                a.flow = nullptr; a.fps = 0; a.ld = 0;
+                hipLaunchKernelGGL(tw_span_scan<false>, dim3(npairs), dim3(1024), 0, st, a);
             } break;
         }
         return TW_OK;

@@ -113,6 +113,27 @@ __device__ __forceinline__ void xcd_remap_cm(int& bx, int& by, int& bz)
     bz = (int)(t / gx);
 }
 
+// A kernel BODY's view of its launch grid: the plain kernels hand their body the hardware grid, the twin kernels (two bodies
+// in one launch, below) give each body a virtual one — gx x gy x gz workgroups numbered b = 0 .. n-1 in launch order, whose
+// tile rows / images start at (y0, z0) of the body's full problem (a launch may cover a band of it).
+struct VGrid {
+    unsigned gx, gy, gz, y0, z0;
+};
+__device__ __forceinline__ VGrid hw_grid() { return VGrid{gridDim.x, gridDim.y, gridDim.z, 0u, 0u}; }
+__device__ __forceinline__ unsigned hw_block() { return blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z); }
+// xcd_remap over a virtual grid (the b-th workgroup of the launch goes to XCD b & 7: a twin launch pads its first part to a
+// multiple of 8 workgroups so that this also holds for the second part's own numbering)
+__device__ __forceinline__ void xcd_remap_v(const VGrid& g, unsigned b, int& bx, int& by, int& bz)
+{
+    const unsigned n = g.gx * g.gy * g.gz;
+    const unsigned xcd = b & 7u, q = n >> 3, r = n & 7u;
+    b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+    bx = (int)(b % g.gx);
+    const unsigned t = b / g.gx;
+    by = (int)(t % g.gy + g.y0);
+    bz = (int)(t / g.gy + g.z0);
+}
+
 // borderInterpolate(p, len, BORDER_REFLECT_101)
 __device__ __forceinline__ int reflect101(int p, int len)
 {
@@ -971,13 +992,13 @@ struct PyrK3fArgs {
     int aligned4;
 };
 
-__global__ __launch_bounds__(256) void tw_pyr_k3f(PyrK3fArgs a)
+__device__ __forceinline__ void tw_pyr_k3f_body(const PyrK3fArgs& a, const int bx_, const int by_, const int bz_)
 {
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // tx = lane: a wave is 64 consecutive 4-pixel groups of level 1
-    const int ox = (blockIdx.x * 64 + tx) * 4;
-    const uint8_t* __restrict__ src = a.srcs[blockIdx.z];
+    const int ox = (bx_ * 64 + tx) * 4;
+    const uint8_t* __restrict__ src = a.srcs[bz_];
     const bool in_w = ox < a.w1;  // lanes past the row end stay active for the lane exchange, they only skip memory
-    const int oy = blockIdx.y * 4 + ty;
+    const int oy = by_ * 4 + ty;
     if (oy >= a.h1) return;  // wave-uniform
     const int sx = 2 * ox;   // first source column of the thread's 8
     const bool own_ok = a.aligned4 && sx + 7 < a.w0;
@@ -1037,7 +1058,7 @@ __global__ __launch_bounds__(256) void tw_pyr_k3f(PyrK3fArgs a)
             sum += b00 + b01 + b10 + b11;
             o[i] = sum * 0.25f;
         }
-        float* d = a.dst1 + blockIdx.z * a.zs1 + (long long)oy * a.ld1 + ox;
+        float* d = a.dst1 + bz_ * a.zs1 + (long long)oy * a.ld1 + ox;
         if (ox + 3 < a.w1) *(f32x4*)d = f32x4{o[0], o[1], o[2], o[3]};
         else
             for (int j = 0; j < 4; j++)
@@ -1051,7 +1072,7 @@ __global__ __launch_bounds__(256) void tw_pyr_k3f(PyrK3fArgs a)
         float o[8];
 #pragma unroll
         for (int j = 0; j < 8; j++) o[j] = (rfa[q][j] + rfa[q + 2][j]) * a.a1 + rfa[q + 1][j] * a.a0;
-        float* d = a.dst0 + blockIdx.z * a.zs0 + (long long)y0 * a.ld0 + sx;
+        float* d = a.dst0 + bz_ * a.zs0 + (long long)y0 * a.ld0 + sx;
         if (sx + 7 < a.w0) {
             *(f32x4*)d = f32x4{o[0], o[1], o[2], o[3]};
             *(f32x4*)(d + 4) = f32x4{o[4], o[5], o[6], o[7]};
@@ -1061,6 +1082,7 @@ __global__ __launch_bounds__(256) void tw_pyr_k3f(PyrK3fArgs a)
         }
     }
 }
+__global__ __launch_bounds__(256) void tw_pyr_k3f(PyrK3fArgs a) { tw_pyr_k3f_body(a, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z); }
 
 // =====================================================================================================
 // K5  tw_polyexp<N> : FarnebackPolyExp (optflowgf.cpp) — the roofline-graded kernel, 24 B/px algorithmic.
@@ -1218,7 +1240,7 @@ __device__ __forceinline__ f32x2 pe_mad(f32x2 a, float b, f32x2 c)
     else return a * b + c;
 }
 template <int N, int TH, int F32ACC = 0>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) void tw_polyexp_pk(PolyArgs a)
+__device__ __forceinline__ void tw_polyexp_pk_body(const PolyArgs& a, const VGrid& vg, const unsigned vb)
 {
     constexpr bool FUSE = F32ACC == 2;
     constexpr int RP = TH / 2, NW = TH + 2 * N, NPA = NW / 2, NPB = NW / 2 - 1;
@@ -1226,7 +1248,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
     __shared__ __attribute__((aligned(16))) f32x2 sm[3][RP][PE_COLS];
     const int tid = threadIdx.x;
     int bx, by, bz;
-    xcd_remap(bx, by, bz);
+    xcd_remap_v(vg, vb, bx, by, bz);
     const int x0 = bx * PE_TW, y0 = by * TH;
     const float* __restrict__ src = a.src + bz * a.ps;
     float* __restrict__ dst = a.dst + bz * 5 * a.ps;
@@ -1467,6 +1489,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
         }
     }
 }
+template <int N, int TH, int F32ACC = 0>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) void tw_polyexp_pk(PolyArgs a)
+{
+    tw_polyexp_pk_body<N, TH, F32ACC>(a, hw_grid(), hw_block());
+}
 
 // =====================================================================================================
 // FarnebackUpdateMatrices for one pixel (optflowgf.cpp): warp R1 by the flow (bilinear gather of 5
@@ -1621,13 +1648,13 @@ struct UpdArgs {
 };
 
 template <bool UPSAMPLE, int NY>
-__global__ __launch_bounds__(256) void tw_update_matrices(UpdArgs a)
+__device__ __forceinline__ void tw_update_matrices_body(const UpdArgs& a, const VGrid& vg, const unsigned vb)
 {
     // One lane = NY pixels of one column (rows 4 apart).  Everything that does not depend on the flow (the R0
     // coefficients, the coarse flow taps) is loaded first and without branches, so that a wave has two
     // dependent memory round trips (flow -> gather) instead of three and NY x the loads in flight.
     int bx, by, z;
-    xcd_remap(bx, by, z);  // an XCD works on a contiguous band of rows: the R1 rows a tile gathers stay in its L2
+    xcd_remap_v(vg, vb, bx, by, z);  // an XCD works on a contiguous band of rows: the R1 rows a tile gathers stay in its L2
     const int x = bx * 64 + (threadIdx.x & 63);
     const int yb = by * (4 * NY) + (threadIdx.x >> 6);
     if (x >= a.w || yb >= a.h) return;
@@ -1706,6 +1733,11 @@ __global__ __launch_bounds__(256) void tw_update_matrices(UpdArgs a)
             for (int c = 0; c < 5; c++) st_stream<0>(Mo + o[j] + c * a.ps, M[j][c]);
         }
     }
+}
+template <bool UPSAMPLE, int NY>
+__global__ __launch_bounds__(256) void tw_update_matrices(UpdArgs a)
+{
+    tw_update_matrices_body<UPSAMPLE, NY>(a, hw_grid(), hw_block());
 }
 
 // =====================================================================================================
@@ -2981,7 +3013,7 @@ __global__ __launch_bounds__(COLS) __attribute__((amdgpu_waves_per_eu(WPE, 8))) 
 //   Same LDS layout, same operation order per value; twice the halo overhead at COLS = 64 is irrelevant here.
 // -----------------------------------------------------------------------------------------------------
 template <int MH, int COLS, int HALO, int TH>
-__global__ __launch_bounds__(5 * COLS) void tw_blur_solve_pp(BlurArgs a)
+__device__ __forceinline__ void tw_blur_solve_pp_body(const BlurArgs& a, const VGrid& vg, const unsigned vb)
 {
     constexpr int TW = COLS - 2 * HALO;
     constexpr int NW = TH + 2 * MH;
@@ -2989,7 +3021,7 @@ __global__ __launch_bounds__(5 * COLS) void tw_blur_solve_pp(BlurArgs a)
     __shared__ __attribute__((aligned(16))) float sm[5][TH][COLS];
     const int tid = threadIdx.x, ch = tid / COLS, ct = tid - ch * COLS;
     int bx, by, z;
-    xcd_remap(bx, by, z);
+    xcd_remap_v(vg, vb, bx, by, z);
     const int x0 = bx * TW - a.xsh, y0 = by * TH;
     const WinCoef& c = a.c;
     const float* __restrict__ Min = a.Min + (long long)z * 5 * a.ps;
@@ -3101,6 +3133,62 @@ __global__ __launch_bounds__(5 * COLS) void tw_blur_solve_pp(BlurArgs a)
                 for (int cc = 0; cc < 5; cc++) Mout[o + cc * a.ps] = M[cc];
             }
         }
+    }
+}
+template <int MH, int COLS, int HALO, int TH>
+__global__ __launch_bounds__(5 * COLS) void tw_blur_solve_pp(BlurArgs a)
+{
+    tw_blur_solve_pp_body<MH, COLS, HALO, TH>(a, hw_grid(), hw_block());
+}
+
+// -----------------------------------------------------------------------------------------------------
+// Twin launches (round 5, the single-pair schedule of BASELINE config 2): TWO kernel bodies in one launch.  A single pair's
+//   coarse-level flow chain is a dozen dependent launches of 5-10 us that use a twentieth of the chip; the image-only work of
+//   the finer levels (their polynomial expansions, the level 0 / 1 images) used to run beside it from a second stream, whose
+//   cross-queue hand-offs cost tens of microseconds on this runtime and whose full-chip launches took the chain's workgroup
+//   slots (profiles/r03_latency.md).  Kernels of one queue never overlap (hipExtAnyOrderLaunch is not honoured on gfx9:
+//   tools/ubench/anyorder.hip), so the overlap is made inside the launch: workgroups [0, nA) run the chain body (dispatched
+//   first), the rest a BAND of the image-only body.  Part A is padded to a multiple of 8 workgroups (see xcd_remap_v).  The
+//   bodies are the plain kernels' bodies: same values.  Threads past a body's own workgroup size exit at once (whole waves).
+// -----------------------------------------------------------------------------------------------------
+// a band of the polynomial expansion by itself (a side job no chain kernel was left to carry)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) void tw_polyexp_band(PolyArgs pa, VGrid g)
+{
+    tw_polyexp_pk_body<7, 8, 0>(pa, g, blockIdx.x);
+}
+struct TwinGrid {
+    VGrid a, b;
+    unsigned nA, nA8;  // workgroups of part A, rounded up to a multiple of 8
+};
+// chain: FarnebackUpdateMatrices (256 threads) | side: a band of the polynomial expansion (256 threads)
+template <bool UPSAMPLE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) void tw_twin_upd_poly(UpdArgs ua, PolyArgs pa, TwinGrid t)
+{
+    if (blockIdx.x < t.nA8) {
+        if (blockIdx.x < t.nA) tw_update_matrices_body<UPSAMPLE, 2>(ua, t.a, blockIdx.x);
+    } else {
+        tw_polyexp_pk_body<7, 8, 0>(pa, t.b, blockIdx.x - t.nA8);
+    }
+}
+// chain: plane-parallel window average + solve (320 threads) | side: a band of the polynomial expansion (256 threads)
+__global__ __launch_bounds__(320) __attribute__((amdgpu_waves_per_eu(3, 8))) void tw_twin_pp_poly(BlurArgs ba, PolyArgs pa, TwinGrid t)
+{
+    if (blockIdx.x < t.nA8) {
+        if (blockIdx.x < t.nA) tw_blur_solve_pp_body<15, 64, 16, 8>(ba, t.a, blockIdx.x);
+    } else {
+        if (threadIdx.x >= 256) return;
+        tw_polyexp_pk_body<7, 8, 0>(pa, t.b, blockIdx.x - t.nA8);
+    }
+}
+// chain: the coarsest level's polynomial expansion | side: levels 0 and 1 of the images (tw_pyr_k3f, 256 threads, no remap)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) void tw_twin_poly_k3f(PolyArgs pa, PyrK3fArgs ka, TwinGrid t)
+{
+    if (blockIdx.x < t.nA8) {
+        if (blockIdx.x < t.nA) tw_polyexp_pk_body<7, 8, 0>(pa, t.a, blockIdx.x);
+    } else {
+        const unsigned b = blockIdx.x - t.nA8;
+        const unsigned bx = b % t.b.gx, r = b / t.b.gx;
+        tw_pyr_k3f_body(ka, (int)bx, (int)(r % t.b.gy), (int)(r / t.b.gy));
     }
 }
 
@@ -3710,10 +3798,15 @@ struct ScanArgs {
     int* count;    // [pairs]
     ScanRec* rec;  // pair z at rec + z*rec_zs
     long long rec_zs;
+    // DIRECT (a single pair: no tw_span_gather launch): the samples come straight from the level-0 flow planes
+    const float* flow;  // pair z: 2 planes at flow + z*2*fps
+    long long fps;
+    int ld;
 };
 
 constexpr int SCAN_IT = 32;  // iterations of 1024 points per round
 
+template <bool DIRECT>
 __global__ __launch_bounds__(1024) void tw_span_scan(ScanArgs a)
 {
     __shared__ int wsum[SCAN_IT * 16];
@@ -3721,7 +3814,14 @@ __global__ __launch_bounds__(1024) void tw_span_scan(ScanArgs a)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int z = blockIdx.x;
     const int G = a.gw * a.gh;
-    const float2* __restrict__ g = a.g + (long long)z * G;
+    const float2* __restrict__ gdense = a.g + (long long)z * G;
+    const float* __restrict__ fx = DIRECT ? a.flow + (long long)z * 2 * a.fps : nullptr;
+    auto sample = [&](int idx) -> float2 {
+        if (!DIRECT) return gdense[idx];
+        const int gy = idx / a.gw, gx = idx - gy * a.gw;
+        const long long o = (long long)(gy * a.span) * a.ld + gx * a.span;
+        return float2{fx[o], fx[o + a.fps]};
+    };
     ScanRec* __restrict__ rec = a.rec + (long long)z * a.rec_zs;
     int base_out = 0;
     for (int base = 0; base < G; base += SCAN_IT * 1024) {
@@ -3733,7 +3833,7 @@ __global__ __launch_bounds__(1024) void tw_span_scan(ScanArgs a)
             for (int u = 0; u < 8; u++) {
                 const int idx = base + (i0 + u) * 1024 + tid;
                 v[u] = float2{0.f, 0.f};
-                if (i0 + u < nit && idx < G) v[u] = g[idx];
+                if (i0 + u < nit && idx < G) v[u] = sample(idx);
             }
 #pragma unroll
             for (int u = 0; u < 8; u++) {
@@ -3770,7 +3870,7 @@ __global__ __launch_bounds__(1024) void tw_span_scan(ScanArgs a)
                 const int idx = base + i * 1024 + tid;
                 const int gy = idx / a.gw, gx = idx - gy * a.gw;
                 const int pos = base_out + wsum[i * 16 + wave] + __popcll(b & ((1ull << lane) - 1ull));
-                const float2 vv = g[idx];
+                const float2 vv = sample(idx);
                 ScanRec rr;
                 rr.x = gx * a.span;
                 rr.y = gy * a.span;
