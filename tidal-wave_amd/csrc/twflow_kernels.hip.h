@@ -2259,9 +2259,24 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     constexpr int NQ = OUT / 4;
     const bool hth = tid < 5 * TH * NQ;
     const int hp = hth ? tid / (TH * NQ) : 0, hrem = hth ? tid - hp * (TH * NQ) : 0, hr = hrem / NQ, hq = hrem - hr * NQ;
-    const bool sth = tid < TH * OUT;
-    const int sr = sth ? tid / OUT : 0, sc = sth ? tid - sr * OUT : 0;
+    // (S items 0 .. 767 on waves 0 .. 11, the last 32 on wave 15 — which has no column in V and no pixel in C: with items
+    // 768 .. 799 on wave 12, SIMD 0 ran four S waves and the others three)
+    constexpr int SMAIN = (TH * OUT) / 64 * 64 >= 768 ? 768 : (TH * OUT) / 64 * 64;
+    const int sitem = tid < SMAIN ? tid : (tid >= 960 && tid - 960 < TH * OUT - SMAIN) ? SMAIN + tid - 960 : -1;
+    const bool sth = sitem >= 0;
+    const int sr = sth ? sitem / OUT : 0, sc = sth ? sitem - sr * OUT : 0;
     const int sxo = bx * OUT + sc;
+    auto s_phase = [&](int st, int s0) {
+        const int sy = ys + st * TH + sr;
+        if (sth && sxo < a.w && sy < a.h && !TW_FI_SKIP(8)) {
+            const double g11 = blk[s0][0][sr][sc], g12 = blk[s0][1][sr][sc], g22 = blk[s0][2][sr][sc],
+                         h1 = blk[s0][3][sr][sc], h2 = blk[s0][4][sr][sc];
+            const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
+            const long long o = (long long)sy * a.ld + sxo;
+            fout[o] = (float)((g11 * h2 - g12 * h1) * idet);
+            fout[o + a.fps_out] = (float)((g22 * h1 - g12 * h2) * idet);
+        }
+    };
 
     // H of one item: (plane hp, row hr, 4-pixel group hq): 36-value window of block bX, four sums into block s0; WITH_LOADS:
     // the taps of planes 3 and 4 of the thread's phase-C pixel behind the first two pixels (main waves only)
@@ -2297,7 +2312,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     };
 
     if (tid >= 960) {
-        // ---- wave 15: no column in V, no pixel in C or S; 40 of the 1 000 H items.  A loop of its own (three barriers per
+        // ---- wave 15: no column in V, no pixel in C; 40 of the 1 000 H items and the last 32 S pixels.  A loop of its own (three barriers per
         // step, like the others).  Tried here and dropped: an L2 PREFETCH — this otherwise idle wave touching one dword
         // of every 128-byte line the next chunk's loads will hit (504 lanes, 9 wave-loads per step) — made the launch
         // 10 % SLOWER (46.7 against 42.3 us per 1080p pair, end to end +1.6 % instead of +7.5 %; gpurun_out/r5s): the
@@ -2308,6 +2323,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
             __syncthreads();  // (V)
             if (hth && !TW_FI_SKIP(4)) h_phase(s0, bX, std::false_type());
             __syncthreads();  // (H)
+            s_phase(st, s0);
             __syncthreads();  // (C, S)
         }
         return;
@@ -2378,17 +2394,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
         // ---- phase B2: S — one pixel per thread from block Y; C — chunk st + NCH into block X; the next chunk's addresses ----
         // (S first: the taps of planes 3 and 4 went out in the middle of H and get S's time to arrive before the combine
         // waits for them)
-        {
-            const int sy = ys + st * TH + sr;
-            if (sth && sxo < a.w && sy < a.h && !TW_FI_SKIP(8)) {
-                const double g11 = blk[s0][0][sr][sc], g12 = blk[s0][1][sr][sc], g22 = blk[s0][2][sr][sc],
-                             h1 = blk[s0][3][sr][sc], h2 = blk[s0][4][sr][sc];
-                const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
-                const long long o = (long long)sy * a.ld + sxo;
-                fout[o] = (float)((g11 * h2 - g12 * h1) * idet);
-                fout[o + a.fps_out] = (float)((g22 * h1 - g12 * h2) * idet);
-            }
-        }
+        s_phase(st, s0);
         __builtin_amdgcn_sched_barrier(0);
         TW_FI_STAMP(5);
         if (cth) {
