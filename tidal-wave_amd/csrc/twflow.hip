@@ -413,6 +413,7 @@ struct tw_engine {
     size_t lat_cap = 0;  // floats in lat_I (lat_R holds 5x)
     std::vector<hipEvent_t> lat_ev;
     int lat_s2_max = 1000;  // TW_LAT_S2_LEVELS: finest..this level's image-only work goes to the second stream
+    int fi_nt = 1024;   // TW_FI_NT=512 (variants library): tw_flow_iter as two 512-thread workgroups per CU on 64-output strips (A/B)
     int lat_fused = 1;  // TW_LAT_FUSED=0: the two-stream single-pair schedule of rounds 2-4 instead of the twin launches (A/B)
     int lat_graph = 0;  // TW_LAT_GRAPH=1: replay the single-pair schedule from a captured hipGraph (measured SLOWER on
                         // ROCm 7.2: 0.55 ms vs 0.37 ms — profiles/r03_latency.md — so it is opt-in, kept for re-measuring)
@@ -1132,7 +1133,8 @@ void launch_flow_iter(tw_engine* e, hipStream_t st, int w, int h, int ld, long l
     a.c = e->wc;
     if (const char* ev = getenv("TW_FI_SKIP")) a.dbg_skip = atoi(ev);  // variants library only (timing experiments)
     a.dbg = (unsigned long long*)e->dbg_stamps;                        // TW_DEBUG_STAMPS=1, variants library only
-    constexpr int OUT = FI_SC - 30;
+    const int OUT = (e->fi_nt == 512 ? FI_SC_512 : FI_SC) - 30;
+    const int slots = e->cu_count * (e->fi_nt == 512 ? 2 : 1);  // workgroups resident at once
     const int nstrips = (w + OUT - 1) / OUT, nsteps = (h + FI_TH - 1) / FI_TH;
     // Row segments per strip: one 1024-thread workgroup per CU is resident, so the launch runs in rounds of (CU count)
     // workgroups; a segment pays NCH = 7 chunks of M for its window's warm-up.  Take the split (1 .. 4) with the least
@@ -1143,7 +1145,7 @@ void launch_flow_iter(tw_engine* e, hipStream_t st, int w, int h, int ld, long l
         const int nt = (nsteps + sg - 1) / sg;
         if (sg > 1 && nt < 16) break;
         const long long wgs = (long long)nstrips * sg * npairs;
-        const long long rounds = (wgs + e->cu_count - 1) / e->cu_count;
+        const long long rounds = (wgs + slots - 1) / slots;
         const double cost = (double)rounds * (nt + 7 * 0.25);  // a warm-up chunk is a quarter of a step (phase C only)
         if (cost < best_cost) {
             best_cost = cost;
@@ -1166,6 +1168,16 @@ void launch_flow_iter(tw_engine* e, hipStream_t st, int w, int h, int ld, long l
         a.beta = ups->beta;
         a.xmax = ups->xmax;
         a.scale = ups->scale;
+    }
+#ifdef TW_VARIANTS
+    if (e->fi_nt == 512) {  // measured 23 % slower (profiles/r05_m_free.md): variants library only
+        if (ups) hipLaunchKernelGGL((tw_flow_iter<15, 1, 512>), grid, dim3(512), 0, st, a);
+        else if (a.zero_flow) hipLaunchKernelGGL((tw_flow_iter<15, 2, 512>), grid, dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((tw_flow_iter<15, 0, 512>), grid, dim3(512), 0, st, a);
+        return;
+    }
+#endif
+    if (ups) {
         hipLaunchKernelGGL((tw_flow_iter<15, 1>), grid, dim3(1024), 0, st, a);
     } else if (a.zero_flow) {
         hipLaunchKernelGGL((tw_flow_iter<15, 2>), grid, dim3(1024), 0, st, a);
@@ -1494,7 +1506,8 @@ tw_status flush_ctx(tw_engine* e, Ctx& c)
     auto level_mfree = [&](int k, int nc) -> bool {
         const LevelPlan& L = pl->lv[k];
         const bool grid_only = k == 0 && it > 0 && e->scan_fused && c.span == 10 && e->win_m == 15 && !e->box;
-        const long long fi_wgs = (long long)((L.w + FI_SC - 31) / (FI_SC - 30)) * std::min(4, std::max(1, L.h / (16 * FI_TH))) * nc;
+        const int fi_out = (e->fi_nt == 512 ? FI_SC_512 : FI_SC) - 30;
+        const long long fi_wgs = (long long)((L.w + fi_out - 1) / fi_out) * std::min(4, std::max(1, L.h / (16 * FI_TH))) * nc;
         return e->mfree && !lat && it > (grid_only ? 1 : 0) && flow_iter_eligible(e, L.w, L.h) &&
                (fi_wgs * 4 >= (long long)e->cu_count * 3 || e->mfree == 2) &&
                (e->mfree_min_px <= 0 || (long long)L.w * L.h >= e->mfree_min_px);
@@ -2265,6 +2278,9 @@ tw_status tw_engine_create(int device, const tw_params* params, int slots, tw_en
     if (const char* ev = getenv("TW_LATENCY_MIN_PX")) e->lat_min_px = atoll(ev);
     if (const char* ev = getenv("TW_LAT_GRAPH")) e->lat_graph = atoi(ev) ? 1 : 0;
     if (const char* ev = getenv("TW_LAT_FUSED")) e->lat_fused = atoi(ev) ? 1 : 0;
+#ifdef TW_VARIANTS
+    if (const char* ev = getenv("TW_FI_NT")) e->fi_nt = atoi(ev) == 512 ? 512 : 1024;
+#endif
     if (const char* ev = getenv("TW_LAT_S2_LEVELS")) e->lat_s2_max = atoi(ev);
     // the main stream carries the dependent flow chain: highest priority, so that its small launches are not queued
     // behind the second stream's image-only work

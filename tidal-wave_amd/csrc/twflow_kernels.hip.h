@@ -2033,6 +2033,9 @@ __global__ __launch_bounds__(COLS) __attribute__((amdgpu_waves_per_eu(4, 8))) vo
 //   a level: what tw_update_matrices<true> fuses), computed in place of the flow load; zero_flow: the coarsest level.
 // -----------------------------------------------------------------------------------------------------
 constexpr int FI_TH = 5, FI_SC = 190, FI_PITCH = 192;
+// NT = 512 (TW_FI_NT=512, A/B): the same kernel as TWO 512-thread workgroups per CU on strips of 94 columns (64 outputs), 76.8 KB of
+// LDS each — a workgroup's barrier phases then overlap with the other workgroup's, for 1.47 x instead of 1.19 x halo columns
+constexpr int FI_SC_512 = 94, FI_PITCH_512 = 96;
 struct FlowIterArgs {
     const float* R;        // pair z: R0 = R + (2z)*5ps, R1 = R0 + 5ps
     const float* flow_in;  // pair z: 2 planes at flow_in + z*2*fps_in
@@ -2061,7 +2064,7 @@ struct FlowIterArgs {
 // stamp i (0..7) of step st, waves 0 and 9, workgroups 0..31 (linear block id), steps 40..47
 #define TW_FI_STAMP(i)                                                                                                   \
     do {                                                                                                                 \
-        if (a.dbg && (tid == 0 || tid == 576) && fi_blin < 32 && st >= 40 && st < 48)                                      \
+        if (a.dbg && (tid == 0 || tid == NT / 2 + 64) && fi_blin < 32 && st >= 40 && st < 48)                              \
             a.dbg[(((size_t)fi_blin * 2 + (tid ? 1 : 0)) * 8 + (st - 40)) * 8 + (i)] = __builtin_amdgcn_s_memtime();       \
     } while (0)
 #else
@@ -2072,12 +2075,16 @@ struct FlowIterArgs {
 // load at all).  A template parameter, not a runtime flag: with the three sources behind one join the compiler copied the
 // freshly loaded flow into the loop-carried registers AFTER the join — an s_waitcnt vmcnt(0) on loads issued a few
 // instructions earlier, in every step.
-template <int MH, int MODE>
-__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) void tw_flow_iter(FlowIterArgs a)
+template <int MH, int MODE, int NT = 1024>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void tw_flow_iter(FlowIterArgs a)
 {
     constexpr bool UPS = MODE == 1;
-    constexpr int TH = FI_TH, SC = FI_SC, P = FI_PITCH, OUT = SC - 2 * MH, RING = TH + 2 * MH, NCH = RING / TH, NB = NCH + 1;
-    static_assert(RING % TH == 0 && SC <= P && TH * SC <= 1024 && TH == 5 && OUT % 4 == 0 && 5 * TH * (OUT / 4) <= 1024 && (NB & (NB - 1)) == 0, "geometry");
+    constexpr int TH = FI_TH, SC = NT == 1024 ? FI_SC : FI_SC_512, P = NT == 1024 ? FI_PITCH : FI_PITCH_512, OUT = SC - 2 * MH,
+                  RING = TH + 2 * MH, NCH = RING / TH, NB = NCH + 1;
+    static_assert(RING % TH == 0 && SC <= P && TH * SC <= NT && TH == 5 && OUT % 4 == 0 && 5 * TH * (OUT / 4) <= NT && (NB & (NB - 1)) == 0, "geometry");
+    // waves with a column in V / a pixel in C; a last wave without one (NT = 1024: wave 15) runs a loop of its own below
+    constexpr int VWAVES = (TH * SC + 63) / 64;
+    constexpr bool SPLIT = VWAVES * 64 < NT;
     // NB = 8 equal blocks of [plane][row][column]: chunk k of M lives in block k % 8; the eighth block is the spare that
     // takes the vertical sums of a step, and the block of the chunk a step retires takes its horizontal sums:
     //   step st:  V reads chunks st .. st+6 (blocks (st+j) % 8) and writes block X = (st+7) % 8;  H reads X and writes
@@ -2261,8 +2268,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     const int hp = hth ? tid / (TH * NQ) : 0, hrem = hth ? tid - hp * (TH * NQ) : 0, hr = hrem / NQ, hq = hrem - hr * NQ;
     // (S items 0 .. 767 on waves 0 .. 11, the last 32 on wave 15 — which has no column in V and no pixel in C: with items
     // 768 .. 799 on wave 12, SIMD 0 ran four S waves and the others three)
-    constexpr int SMAIN = (TH * OUT) / 64 * 64 >= 768 ? 768 : (TH * OUT) / 64 * 64;
-    const int sitem = tid < SMAIN ? tid : (tid >= 960 && tid - 960 < TH * OUT - SMAIN) ? SMAIN + tid - 960 : -1;
+    constexpr int SMAIN = SPLIT ? (TH * OUT) / 64 * 64 : TH * OUT;
+    const int sitem = tid < SMAIN ? tid : (SPLIT && tid >= VWAVES * 64 && tid - VWAVES * 64 < TH * OUT - SMAIN) ? SMAIN + tid - VWAVES * 64 : -1;
     const bool sth = sitem >= 0;
     const int sr = sth ? sitem / OUT : 0, sc = sth ? sitem - sr * OUT : 0;
     const int sxo = bx * OUT + sc;
@@ -2311,7 +2318,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
         *(f32x4*)&blk[s0][hp][hr][4 * hq] = o;
     };
 
-    if (tid >= 960) {
+    if (SPLIT && tid >= VWAVES * 64) {
         // ---- wave 15: no column in V, no pixel in C; 40 of the 1 000 H items and the last 32 S pixels.  A loop of its own (three barriers per
         // step, like the others).  Tried here and dropped: an L2 PREFETCH — this otherwise idle wave touching one dword
         // of every 128-byte line the next chunk's loads will hit (504 lanes, 9 wave-loads per step) — made the launch
