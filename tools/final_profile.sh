@@ -56,5 +56,8 @@ done
 python3 tools/pmc_kernel_traffic.py "$out/pmc5_FETCH_SIZE" "$out/pmc5_WRITE_SIZE" "tw_blur_solve4y<25" 16 "$out/traffic_cfg5.json" "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 tools/bench_config5.py 16 2 (tools/final_profile.sh)" > "$out/traffic_cfg5.log" 2>&1
 python3 tools/clock_watch.py "$out/clock_power.json" -- python3 bench.py --steps 40 --warmup 4 --no-cpu-baseline --no-extras > "$out/clock_power.log" 2>&1
 python3 tools/latency.py 40 > "$out/latency.txt" 2>&1
+echo "two-stream schedule (TW_LAT_FUSED=0):" >> "$out/latency.txt"; TW_LAT_FUSED=0 python3 tools/latency.py 40 >> "$out/latency.txt" 2>&1
+timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d "$out/lat_trace" -o run -- python3 tools/latency.py 10 1 > "$out/lat_trace.log" 2>&1
+python3 tools/timeline.py "$out/lat_trace" 23 > "$out/lat_timeline.txt" 2>&1
 python3 tools/polyexp_f32.py > "$out/polyexp_f32.json" 2> "$out/polyexp_f32.err"
 echo done; cut -c1-400 "$out/bench.json"
