@@ -1186,9 +1186,15 @@ void launch_flow_iter(tw_engine* e, hipStream_t st, int w, int h, int ld, long l
     }
 }
 
+// span-grid samples a tw_blur_solve4 launch stores next to the flow (the single-pair schedule's last level-0 launch)
+struct GridOut {
+    float2* g;
+    int span, gw, gh;
+    bool* used;  // set if the launch took a kernel that stores them (the caller launches tw_span_gather otherwise)
+};
 void launch_blur(tw_engine* e, hipStream_t st, int w, int h, int ld, long long ps, const float* Min, float* Mout,
                  float* flow, const float* R, int update, int level, int npairs, double* Vbox = nullptr,
-                 const SideJob* side = nullptr, bool* side_used = nullptr)
+                 const SideJob* side = nullptr, bool* side_used = nullptr, const GridOut* go = nullptr)
 {
     BlurArgs a;
     a.Min = Min;
@@ -1207,7 +1213,21 @@ void launch_blur(tw_engine* e, hipStream_t st, int w, int h, int ld, long long p
     a.m = e->win_m;
     a.nomask = e->blur_nomask;
     a.cm = e->blur_cm;
+    a.grid = nullptr;
+    a.gspan = a.gw = a.gh = 0;
+    a.gmagic = 0;
     a.c = e->wc;
+    // tw_blur_solve4<15, ...> stores the span-grid samples next to the flow when asked to (GridOut)
+    auto set_grid_out = [&]() {
+        if (go && go->span > 1 && w < 65536 && h < 65536) {
+            a.grid = go->g;
+            a.gspan = go->span;
+            a.gw = go->gw;
+            a.gh = go->gh;
+            a.gmagic = (unsigned)((0x100000000ull + (unsigned)go->span - 1) / (unsigned)go->span);
+            *go->used = true;
+        }
+    };
     const int gy = (h + BS_TH - 1) / BS_TH;
     const bool wide = w > 480;  // 224-column tiles; narrow levels use 96-column tiles (less edge waste)
     if (e->box) {
@@ -1277,7 +1297,10 @@ void launch_blur(tw_engine* e, hipStream_t st, int w, int h, int ld, long long p
             a.xsh = ((w + 16 + tw - 1) / tw == (w + tw - 1) / tw) ? 16 : 0;
             a.rot = a.xsh;
             const dim3 grid((w + a.xsh + tw - 1) / tw, (h + th - 1) / th, npairs);
-            if (small == 1) hipLaunchKernelGGL((tw_blur_solve4<15, 128, 16, 8, true>), grid, dim3(128), 0, st, a);
+            if (small == 1) {
+                set_grid_out();
+                hipLaunchKernelGGL((tw_blur_solve4<15, 128, 16, 8, true>), grid, dim3(128), 0, st, a);
+            }
 #ifdef TW_VARIANTS
             else if (small == 2) hipLaunchKernelGGL((tw_blur_solve4<15, 128, 16, 4, true>), grid, dim3(128), 0, st, a);
             else if (small == 3) hipLaunchKernelGGL((tw_blur_solve4<15, 64, 16, 4, true>), grid, dim3(64), 0, st, a);
@@ -1340,6 +1363,7 @@ void launch_blur(tw_engine* e, hipStream_t st, int w, int h, int ld, long long p
             }
         }
 #endif
+        set_grid_out();
         if (wide) hipLaunchKernelGGL((tw_blur_solve4<15, 256, 16, 8, true>), dim3((w + a.xsh + 223) / 224, gy, npairs), dim3(256), 0, st, a);
         else hipLaunchKernelGGL((tw_blur_solve4<15, 128, 16, 8, true>), dim3((w + a.xsh + 95) / 96, gy, npairs), dim3(128), 0, st, a);
     } else if (e->win_m == 25) {
@@ -1598,10 +1622,20 @@ tw_status flush_ctx(tw_engine* e, Ctx& c)
         // carriers: the update + `it` window launches of levels 3 and 2, and level 1's update
         const int carriers = 2 * (it + 1) + 1;
         const int gy2 = (pl->lv[2].h + PE_TH - 1) / PE_TH, gy1 = (pl->lv[1].h + PE_TH - 1) / PE_TH, gy0 = (pl->lv[0].h + PE_TH - 1) / PE_TH;
+        // Few, large jobs on the coarsest level's launches: a chain launch stretches to its side job's own duration plus
+        // ~2 us when it has CUs to spare (level 3: 136 workgroups), but by ~0.7 of the job's when it fills the chip itself
+        // (level 2's window launches: 510 five-wave workgroups) — profiles/r05_single_pair.md.  TW_LAT_BANDS=n: n bands per
+        // level-0 image and level 1 per image (n = 3: the first version's nine jobs on nine carriers)
+        static const int bands_env = getenv("TW_LAT_BANDS") ? atoi(getenv("TW_LAT_BANDS")) : 0;
+        (void)carriers;
         side_poly(2, 0, 2, 0, gy2);
-        side_poly(1, 0, 1, 0, gy1);
-        side_poly(1, 1, 1, 0, gy1);
-        const int nb = std::min(8, std::max(1, (carriers - 3) / 2));  // bands per level-0 image
+        if (bands_env >= 2) {
+            side_poly(1, 0, 1, 0, gy1);
+            side_poly(1, 1, 1, 0, gy1);
+        } else {
+            side_poly(1, 0, 2, 0, gy1);
+        }
+        const int nb = std::min(8, std::max(1, bands_env));  // bands per level-0 image
         const int rows = (gy0 + nb - 1) / nb;
         for (int z = 0; z < 2; z++)
             for (int y0 = 0; y0 < gy0; y0 += rows) side_poly(0, z, 1, y0, std::min(rows, gy0 - y0));
@@ -1663,6 +1697,7 @@ tw_status flush_ctx(tw_engine* e, Ctx& c)
                 // level-0 flow is read afterwards, so the last window average + solve runs at the grid points only
                 const bool grid_only = k == 0 && it > 0 && e->scan_fused && c.span == 10 && e->win_m == 15 && !e->box;
                 bool iterated = false;
+                bool grid_stored = false;  // the last window launch wrote the span-grid samples itself (single pair)
                 // (with the scan-fused last iteration: it - 1 iterations here, then the M of the last flow from
                 // tw_update_matrices<false> into M1 — tw_blur_grid evaluates the window average + solve at the span-grid
                 // points from it; a single iteration has no flow of this level to start from and takes the old launches)
@@ -1745,12 +1780,22 @@ tw_status flush_ctx(tw_engine* e, Ctx& c)
                         side_done(used);
                         continue;
                     }
+                    if (lat && k == 0 && i == it - 1 && c.span > 0 && !grid_only) {
+                        // the launch that stores the final flow stores its span-grid samples too: no tw_span_gather launch
+                        GridOut go{e->d_grid + (size_t)j0 * ((L.w + c.span - 1) / c.span) * ((L.h + c.span - 1) / c.span), c.span,
+                                   (L.w + c.span - 1) / c.span, (L.h + c.span - 1) / c.span, &grid_stored};
+                        launch_blur(e, ls, L.w, L.h, L.ld, L.ps, (i & 1) ? M1 : M0, (i & 1) ? M0 : M1, flow_cur, R, 0, k, nc,
+                                    e->Vd ? e->Vd + ws_lane / 2 * 5 * lane : nullptr, nullptr, nullptr, &go);
+                        continue;
+                    }
                     launch_blur(e, ls, L.w, L.h, L.ld, L.ps, (i & 1) ? M1 : M0, (i & 1) ? M0 : M1, flow_cur, R,
                                 i < it - 1, k, nc, e->Vd ? e->Vd + ws_lane / 2 * 5 * lane : nullptr);
                 }
-                if (k == 0 && c.span > 0 && !grid_only && !lat) {
-                    // grid samples of this chunk -> dense per-pair buffer (the ordered scan runs once per batch;
-                    // a single pair's scan reads the flow planes itself)
+                if (k == 0 && c.span > 0 && !grid_only && !grid_stored) {
+                    // grid samples of this chunk -> dense per-pair buffer (the ordered scan runs once per batch).
+                    // (A scan that samples the flow planes itself — tw_span_scan<true>, TW_SCAN_DIRECT=1 of the variants library — saves this launch and
+                    // costs more than it: one workgroup's 41 472 scattered dwords are 19.5 us on one CU's memory pipe against
+                    // 4.8 + 7.3 us for the gather on 81 workgroups + the scan; gpurun_out/r7lat)
                     GatherArgs g;
                     g.flow = flow_cur;
                     g.fzs = 2 * L.ps;
@@ -1837,9 +1882,15 @@ tw_status flush_ctx(tw_engine* e, Ctx& c)
         a.fps = L.ps;
         a.ld = L.ld;
         const bool grid_only = e->p.pyrIterations > 0 && e->scan_fused && c.span == 10 && e->win_m == 15 && !e->box;
+        (void)grid_only;
         ProfScope pscope(e, st, TW_K_SCAN, 0);
-        if (lat && !grid_only) hipLaunchKernelGGL(tw_span_scan<true>, dim3(n), dim3(1024), 0, st, a);
-        else hipLaunchKernelGGL(tw_span_scan<false>, dim3(n), dim3(1024), 0, st, a);
+#ifdef TW_VARIANTS
+        static const bool scan_direct = getenv("TW_SCAN_DIRECT") != nullptr;
+        if (lat && !grid_only && scan_direct) {
+            hipLaunchKernelGGL(tw_span_scan<true>, dim3(n), dim3(1024), 0, st, a);
+        } else
+#endif
+        hipLaunchKernelGGL(tw_span_scan<false>, dim3(n), dim3(1024), 0, st, a);
     }
     TW_HIP(e, hipEventRecord(c.ev_stop, st));
     if (c.span > 0) {

@@ -1770,6 +1770,12 @@ struct BlurArgs {
     int m;       // runtime m for the generic kernel
     int nomask;  // A/B switch (TW_BLUR_NOMASK=1): compute the lanes that overhang the image as well
     int cm;      // tw_blur_solve4y: column-major tile order inside an XCD's band (xcd_remap_cm)
+    // tw_blur_solve4, single-pair schedule: the launch that stores the level-0 flow also stores its span-grid samples (what
+    // tw_span_gather would read back): grid = pair z's gw x gh float2 at + z*gw*gh, gspan = span, gmagic = ceil(2^32 / span)
+    // (exact quotients for coordinates < 65 536)
+    float2* grid;
+    int gspan, gw, gh;
+    unsigned gmagic;
     WinCoef c;
 };
 
@@ -1984,6 +1990,11 @@ __global__ __launch_bounds__(COLS) __attribute__((amdgpu_waves_per_eu(4, 8))) vo
         if (valid && (!a.update || a.store_flow)) {
             flow[o] = fxv;
             flow[o + a.fps] = fyv;
+            if (a.gspan > 0) {  // wave-uniform
+                const unsigned qx = __umulhi((unsigned)xc, a.gmagic), qy = __umulhi((unsigned)yc, a.gmagic);
+                if (qx * (unsigned)a.gspan == (unsigned)xc && qy * (unsigned)a.gspan == (unsigned)yc)
+                    a.grid[((long long)z * a.gh + qy) * a.gw + qx] = float2{fxv, fyv};
+            }
         }
         if (FUSED) {
             if (a.update) {  // wave-uniform
@@ -3823,6 +3834,7 @@ template <bool DIRECT>
 __global__ __launch_bounds__(1024) void tw_span_scan(ScanArgs a)
 {
     __shared__ int wsum[SCAN_IT * 16];
+    __shared__ int wtot[16];
     __shared__ int round_total;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int z = blockIdx.x;
@@ -3862,17 +3874,19 @@ __global__ __launch_bounds__(1024) void tw_span_scan(ScanArgs a)
             }
         }
         __syncthreads();
-        // exclusive scan of the nit*16 per-wave counts (<= 512 entries) in place
+        // exclusive scan of the nit*16 per-wave counts (<= 512 entries) in place: a shuffle scan inside each wave, then the
+        // totals of the waves before it (two barriers; the log-step scan through LDS this replaces took 27)
         const int ne = nit * 16;
-        int mine = (tid < ne) ? wsum[tid] : 0;
+        const int mine = (tid < ne) ? wsum[tid] : 0;
         int incl = mine;
-        for (int off = 1; off < 512; off <<= 1) {
-            __syncthreads();
-            if (tid < ne) wsum[tid] = incl;
-            __syncthreads();
-            if (tid < ne && tid >= off) incl += wsum[tid - off];
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(incl, off);
+            if (lane >= off) incl += t;
         }
+        if (lane == 63) wtot[wave] = incl;
         __syncthreads();
+        for (int w2 = 0; w2 < wave; w2++) incl += wtot[w2];
         if (tid < ne) wsum[tid] = incl - mine;
         if (tid == ne - 1) round_total = incl;
         __syncthreads();
