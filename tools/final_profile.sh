@@ -27,8 +27,8 @@ tools/sq_probe.sh "$out/sq_flow_iter" 8 3 0 4 > "$out/sq_flow_iter.txt" 2>&1
 tools/sq_probe.sh "$out/sq_flow_iter_ups" 8 3 0 8 > "$out/sq_flow_iter_ups.txt" 2>&1
 python3 tools/sq_report.py "$out/sq_polyexp" "tw_polyexp_pk<7, 8, 0>" 265420800 "tw_polyexp_pk<7,8> @ level 0, 64 pairs (128 images of 1920x1080) per launch" packed > "$out/polyexp_sq.md"
 python3 tools/sq_report.py "$out/sq_blur_fused" tw_blur_solve4 132710400 "tw_blur_solve4<15,256,16,8> fused with the matrix refresh @ level 0, 64 pairs per launch (TW_MFREE=0's kernel; what tw_flow_iter replaces)" > "$out/blur_fused_sq.md"
-python3 tools/sq_report.py "$out/sq_flow_iter" "tw_flow_iter<15, 0>" 132710400 "tw_flow_iter<15,0> (one whole iteration, no M in HBM) @ level 0, 64 pairs per launch" > "$out/flow_iter_sq.md"
-python3 tools/sq_report.py "$out/sq_flow_iter_ups" "tw_flow_iter<15, 1>" 132710400 "tw_flow_iter<15,1> (first iteration of a level: flow upsample fused) @ level 0, 64 pairs per launch" > "$out/flow_iter_ups_sq.md"
+python3 tools/sq_report.py "$out/sq_flow_iter" "tw_flow_iter<15, 0" 132710400 "tw_flow_iter<15,0> (one whole iteration, no M in HBM) @ level 0, 64 pairs per launch" > "$out/flow_iter_sq.md"
+python3 tools/sq_report.py "$out/sq_flow_iter_ups" "tw_flow_iter<15, 1" 132710400 "tw_flow_iter<15,1> (first iteration of a level: flow upsample fused) @ level 0, 64 pairs per launch" > "$out/flow_iter_ups_sq.md"
 python3 tools/fi_stamps.py 4 > "$out/flow_iter_stamps.txt" 2>&1
 # same-lease A/B of the round's two default changes (two runs each, alternating)
 for i in 1 2; do for f in 0 1; do

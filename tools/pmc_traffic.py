@@ -57,7 +57,7 @@ def main():
     # (<15, 0>: 2 of the 3 launches of a level) is then the dominant kernel and takes the "tw_blur_solve" slot bench.py reads
     # (a 1080p pair is 12 strips x 1, 2, 3 or 4 row segments of 1 024 threads: the launch covers the same batch as the
     # polynomial expansion's level-0 launch, whose pairs the grid arithmetic above has already told)
-    fi = [r for r in rows if r[0].startswith("tw_flow_iter<15, 0>") and r[1] % (12 * 1024) == 0]
+    fi = [r for r in rows if r[0].startswith("tw_flow_iter<15, 0") and r[1] % (12 * 1024) == 0]
     if fi and out.get("tw_polyexp"):
         big = max(fi, key=lambda r: (r[1], r[2]))
         out["tw_blur_solve"] = {"bytes_per_launch": round(big[3] + big[4]), "pairs_per_launch": out["tw_polyexp"]["pairs_per_launch"],
