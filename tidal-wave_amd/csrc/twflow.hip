@@ -1574,7 +1574,7 @@ tw_status flush_ctx(tw_engine* e, Ctx& c)
     // the next side job, for the launcher of a chain kernel; side_done launches it by itself if the launcher had no twin
     // measurement: TW_LAT_ALONE=1 every side job as its own launch; =2 also the chain kernels through their twins (empty side)
     static const int side_alone = getenv("TW_LAT_ALONE") ? atoi(getenv("TW_LAT_ALONE")) : 0;
-    static SideJob empty_side;
+    SideJob empty_side = SideJob();  // (a local: engines of several host threads run this function at once)
     empty_side.kind = 1;
     empty_side.g = VGrid{0u, 0u, 0u, 0u, 0u};
     auto side_peek = [&]() -> const SideJob* {
