@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Socket power and shader clock per kernel: each level-0 kernel of the 1080p pipeline runs back to back for about two
 seconds (tw_bench_stage on 64 resident synthetic pairs) while sysfs power / clock are sampled every 50 ms.
-    tools/power_per_kernel.py > profiles/r02_power_per_kernel.md"""
+    tools/power_per_kernel.py > profiles/r05_power_per_kernel.md"""
 import glob
 import os
 import statistics
@@ -41,7 +41,9 @@ def main():
         for name, kc, lv, flags in (r for r in (("tw_pyr_k3<0> (level 0)", T.K_PYR, 0, 0), ("tw_pyr_taps<19> (level 3)", T.K_PYR, 3, 0),
                                     ("tw_polyexp_pk<7,8>", T.K_POLYEXP, 0, 0), ("tw_update_matrices<true,2>", T.K_UPDATE_MATRICES, 0, 0),
                                     ("tw_blur_solve4 fused with the refresh", T.K_BLUR_SOLVE, 0, 0),
-                                    ("tw_blur_solve4 last iteration", T.K_BLUR_SOLVE, 0, 2)) if only in r[0]):
+                                    ("tw_blur_solve4 last iteration", T.K_BLUR_SOLVE, 0, 2),
+                                    ("tw_flow_iter<15,0> (round 5: one whole iteration, no M in HBM)", T.K_BLUR_SOLVE, 0, 4),
+                                    ("tw_flow_iter<15,1> (first iteration of a level: upsample fused)", T.K_BLUR_SOLVE, 0, 8)) if only in r[0]):
             us = e.bench_stage(kc, W, H, lv, 64, 3, flags)
             iters = max(10, int(2.0e6 / us))
             t0 = time.time()
@@ -59,7 +61,7 @@ def main():
         rows.append((name, us, us / 64, statistics.median(x[0] for x in seg) if seg else 0,
                      statistics.median(x[1] for x in seg) if seg else 0, len(seg)))
     cap = read(cards[busy].get("power1_cap", "")) if cards else None
-    print("# Socket power and shader clock per kernel (round 2)\n")
+    print("# Socket power and shader clock per kernel\n")
     print("`python3 tools/power_per_kernel.py`: every kernel runs back to back for about two seconds on 64 resident synthetic")
     print("1080p pairs (`tw_bench_stage`); sysfs `power1_input` / `freq1_input` of the card sampled every 50 ms, the first 0.6 s of")
     print("each run skipped.  Power limit of the card: %s W.\n" % (int(cap) // 1000000 if cap else "?"))
