@@ -237,11 +237,11 @@ def test_host_layer_ceiling_for_eight_gpus_on_a_timed_stub():
     out = _stub_queue_run(16384, 31.3)
     assert out["consumers"] == 8 and out["errors"] == 0 and out["pump"]["delivered"] == 16384
     assert sum(c["pairs"] for c in out["per_consumer"]) == 16384
-    assert out["pairs_per_s"] >= 0.93 * ideal, (out["pairs_per_s"], ideal)
-    assert max(c["idle_frac"] for c in out["per_consumer"]) < 0.08, [c["idle_frac"] for c in out["per_consumer"]]
+    assert out["pairs_per_s"] >= 0.90 * ideal, (out["pairs_per_s"], ideal)
+    assert max(c["idle_frac"] for c in out["per_consumer"]) < 0.12, [c["idle_frac"] for c in out["per_consumer"]]
     assert out["pump"]["latency_mean_us"] < 5000
     short = _stub_queue_run(2048, 31.3)  # configs[3]'s shape: 2 048 pairs over 8 devices
-    assert short["pairs_per_s"] >= 0.75 * ideal, short["pairs_per_s"]
+    assert short["pairs_per_s"] >= 0.70 * ideal, short["pairs_per_s"]
     assert min(c["pairs"] for c in short["per_consumer"]) >= 128, [c["pairs"] for c in short["per_consumer"]]
     fast = _stub_queue_run(65536, 4.0)  # devices 8 x faster than an MI355X: where is the host layer's own ceiling?
     assert fast["pairs_per_s"] >= 4 * ideal, fast["pairs_per_s"]
