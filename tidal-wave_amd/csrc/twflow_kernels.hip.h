@@ -2072,6 +2072,8 @@ struct FlowIterArgs {
 
 #ifdef TW_VARIANTS
 #define TW_FI_SKIP(bit) (a.dbg_skip & (bit))
+// TW_FI_SKIP=16: no workgroup barrier in the step loop (wrong results; what the three barriers of a step cost: 1.5 %)
+#define TW_FI_SYNC() do { if (!TW_FI_SKIP(16)) __syncthreads(); } while (0)
 // stamp i (0..7) of step st, waves 0 and 9, workgroups 0..31 (linear block id), steps 40..47
 #define TW_FI_STAMP(i)                                                                                                   \
     do {                                                                                                                 \
@@ -2080,6 +2082,7 @@ struct FlowIterArgs {
     } while (0)
 #else
 #define TW_FI_SKIP(bit) false
+#define TW_FI_SYNC() __syncthreads()
 #define TW_FI_STAMP(i) do { } while (0)
 #endif
 // MODE 0: input flow from flow_in; 1: the coarser level's flow, upsampled in place of the load (UPS); 2: zero flow (no
@@ -2338,11 +2341,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 #pragma unroll 1
         for (int st = 0; st < nsteps; st++) {
             const int s0 = st & (NB - 1), bX = (st + NCH) & (NB - 1);
-            __syncthreads();  // (V)
+            TW_FI_SYNC();  // (V)
             if (hth && !TW_FI_SKIP(4)) h_phase(s0, bX, std::false_type());
-            __syncthreads();  // (H)
+            TW_FI_SYNC();  // (H)
             s_phase(st, s0);
-            __syncthreads();  // (C, S)
+            TW_FI_SYNC();  // (C, S)
         }
         return;
     }
@@ -2398,7 +2401,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             }
         }
         TW_FI_STAMP(1);
-        __syncthreads();
+        TW_FI_SYNC();
         TW_FI_STAMP(2);
 
         // ---- phase B1: H — (plane, row, 4-pixel group): 36-value window from block X, four sums into block Y ----
@@ -2406,7 +2409,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         // the plane — valid, unused — rather than make the load conditional: see above)
         if (!TW_FI_SKIP(4)) h_phase(s0, bX, std::true_type());
         TW_FI_STAMP(3);
-        __syncthreads();
+        TW_FI_SYNC();
         TW_FI_STAMP(4);
 
         // ---- phase B2: S — one pixel per thread from block Y; C — chunk st + NCH into block X; the next chunk's addresses ----
@@ -2425,7 +2428,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             __builtin_amdgcn_sched_barrier(0);
         }
         TW_FI_STAMP(7);
-        __syncthreads();
+        TW_FI_SYNC();
     };
     float q1[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
     {
