@@ -223,6 +223,22 @@ def live_traffic(mode, timeout=300):
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd="/tmp", env=env)
             if r.returncode != 0:
                 return None
+        # third pass: what the kernels are really bound by — VALU issue share of the SIMD time and the shader
+        # clock they hold, per kernel (tools/pmc_valu.py); a failure here costs only these two fields
+        valu = None
+        try:
+            cmd = [exe, "--kernel-trace", "--pmc"] + VALU_COUNTERS + ["--output-format", "csv", "-d", os.path.join(d, "VALU"), "-o", "run", "--",
+                   sys.executable, os.path.abspath(__file__), "--mode", mode, "--steps", "1", "--warmup", "1", "--batch", "128",
+                   "--no-cpu-baseline", "--no-prof", "--no-extras"]
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd="/tmp", env=env)
+            if r.returncode == 0:
+                vout = os.path.join(d, "valu.json")
+                r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_valu.py"), os.path.join(d, "VALU"), vout],
+                                   capture_output=True, text=True, timeout=120, env=env)
+                if r.returncode == 0 and os.path.exists(vout):
+                    valu = json.load(open(vout))
+        except Exception:
+            valu = None
         out = os.path.join(d, "traffic.json")
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_traffic.py"), os.path.join(d, "FETCH_SIZE"),
                             os.path.join(d, "WRITE_SIZE"), out], capture_output=True, text=True, timeout=120,
@@ -232,6 +248,8 @@ def live_traffic(mode, timeout=300):
         t = json.load(open(out))
         if not t.get("tw_blur_solve") or not t.get("tw_polyexp"):
             return None
+        if valu:
+            t["_valu"] = valu
         t["_provenance"]["source"] = "live: PMC passes run by this bench.py invocation (child runs of --mode %s --steps 1 --batch 128)" % mode
         t["_provenance"]["command"] = ("rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py "
                                        "--mode %s --steps 1 --warmup 1 --batch 128 --no-cpu-baseline --no-prof --no-extras" % mode)
@@ -240,6 +258,32 @@ def live_traffic(mode, timeout=300):
         return None
     finally:
         shutil.rmtree(d, ignore_errors=True)
+
+
+VALU_COUNTERS = ["SQ_INSTS_VALU", "SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64",
+                 "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_CVT", "GRBM_GUI_ACTIVE"]
+# which entry of tools/pmc_valu.py's output prices which roofline object, and the static figures of profiles/ for runs
+# that cannot take their own counters (N > 1, --no-extras, no rocprofv3)
+VALU_KEYS = {"tw_blur_solve": ("tw_flow_iter<15, 0", "tw_blur_solve4<"), "tw_polyexp": ("tw_polyexp_pk",)}
+
+
+def limiter_fields(name, traffic):
+    """`bound` stays the roof `frac` is priced against (HBM: the contract's vocabulary); `limiter` says what the counters say
+    holds the kernel (VERDICT r5 #4)."""
+    v = None
+    for key in VALU_KEYS.get(name, ()):
+        v = (traffic.get("_valu") or {}).get(key)
+        if v:
+            break
+    if not v:
+        return {"limiter": "valu_issue (not HBM): see profiles/r06_flow_iter_sq.md / r05_polyexp_sq.md; no live counter pass in this run",
+                "valu_issue_frac": None, "shader_clock_GHz": None}
+    return {"limiter": "valu_issue at a power-capped clock (not HBM: moved bytes / time is the `frac` above, traffic = 1.0 x the "
+                       "algorithmic bytes)",
+            "valu_issue_frac": v["valu_issue_frac"], "shader_clock_GHz": v["shader_clock_GHz"],
+            "valu_note": "live SQ pass of this run (tools/pmc_valu.py): VALU wave-instructions x measured issue cost (f32 2.2, "
+                         "f64-class / packed f32 4.3 cycles) / (clock cycles x 1024 SIMDs); clock = GRBM_GUI_ACTIVE / 8 / "
+                         "duration under the counters (%s, %.0f us)" % (v["kernel"], v["launch_us_under_pmc"])}
 
 
 def load_traffic():
@@ -263,8 +307,11 @@ def roofline_obj(name, ms, launches, bytes_total, pairs_per_launch, traffic, chu
         # the PMC passes measured launches of tr_pairs pairs; traffic is linear in the pairs of a launch
         tr_pairs = tr["pairs_per_launch"]
         tr_bytes = round(tr["bytes_per_launch"] * pairs_per_launch / tr_pairs)
+    lim = limiter_fields(name, traffic)
     return {"kernel": name + " @level0 (1920x1080)", "bound": "hbm", "achieved": round(gbs, 1),
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+            "limiter": lim["limiter"], "valu_issue_frac": lim["valu_issue_frac"], "shader_clock_GHz": lim["shader_clock_GHz"],
+            "valu_note": lim.get("valu_note"),
             "traffic": tr_bytes, "traffic_pairs_per_launch": tr_pairs,
             "traffic_source": ("live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes run by this bench.py invocation on a "
                                "one-step child run of itself (launches of traffic_pairs_per_launch pairs, scaled to this "
@@ -418,7 +465,7 @@ def config5_4k(twflow, synth, device, batch=16, steps=4, distinct=4):
         e.prof_select(-1, -2)
         per_pair = e.algorithmic_bytes_pair(W5, H5, SPAN)
         it = kw["pyrIterations"]
-        by = e.algorithmic_bytes(twflow.K_BLUR_SOLVE, 0, W5, H5) * it * batch * steps
+        by = e.algorithmic_bytes(twflow.K_BLUR_SOLVE, 0, W5, H5, batch) * it * batch * steps
         v = batch * steps / dt
         roof = None
         # HBM traffic of the 51-tap level-0 launch: two rocprofv3 PMC passes over tools/bench_config5.py (tools/final_profile.sh),
@@ -432,6 +479,13 @@ def config5_4k(twflow, synth, device, batch=16, steps=4, distinct=4):
             gbs = by / (ms * 1e-3) / 1e9
             roof = {"kernel": "tw_blur_solve (51-tap window, winSize 50) @level0 (3840x2160)", "bound": "hbm",
                     "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                    # what the counters say holds it: the 51-tap window average is VALU-issue-bound; `bound`
+                    # stays the roof `frac` is priced against
+                    "limiter": "valu_issue at a power-capped clock (not HBM)",
+                    "valu_issue_frac": ((tr5 or {}).get("_valu") or {}).get("valu_issue_frac"),
+                    "shader_clock_GHz": ((tr5 or {}).get("_valu") or {}).get("shader_clock_GHz"),
+                    "valu_source": ("profiles/traffic_cfg5.json `_valu` (static: one rocprofv3 SQ pass over tools/bench_config5.py, "
+                                    "tools/pmc_valu.py)" if ((tr5 or {}).get("_valu")) else None),
                     "traffic": (round(tr5["bytes_per_launch"] * (it * batch * steps / nl) / tr5["pairs_per_launch"])
                                 if tr5 and tr5.get("pairs_per_launch") else None),
                     "traffic_source": ("profiles/traffic_cfg5.json (static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over "
@@ -814,11 +868,11 @@ def main():
             # over the timed region instead of assuming full launches
             per_pair_launches = 3 if kc == twflow.K_BLUR_SOLVE else 1
             pairs_mine = args.batch * args.steps
-            bytes_total = eng.algorithmic_bytes(kc, 0, W, H) * per_pair_launches * pairs_mine
+            bytes_total = eng.algorithmic_bytes(kc, 0, W, H, args.slots) * per_pair_launches * pairs_mine
             rf = roofline_obj(twflow.KERNEL_NAMES[kc], ms, n, bytes_total, per_pair_launches * pairs_mine / n,
                               traffic, chunk=eng.level_chunk(W, H, 0))
             if rf and kc == twflow.K_BLUR_SOLVE:
-                mfree = eng.algorithmic_bytes(twflow.K_UPDATE_MATRICES, 0, W, H) == 0  # level 0 runs tw_flow_iter
+                mfree = eng.level_runs_flow_iter(W, H, 0, args.slots)  # the schedule's own predicate
                 if mfree:
                     rf["kernel"] = "tw_flow_iter (one whole iteration, no M in HBM) @level0 (1920x1080)"
                     # SURVEY 8(d)'s STAGE model of what the three launches of level 0 replace: three updateMatrices (68 B/px,
@@ -887,7 +941,7 @@ def main():
             pairs_r = args.batch * (resident_extra["steps"] + 1)
             resident_extra["roofline"] = roofline_obj(
                 twflow.KERNEL_NAMES[twflow.K_BLUR_SOLVE], ms_r, n_r,
-                eng.algorithmic_bytes(twflow.K_BLUR_SOLVE, 0, W, H) * 3 * pairs_r, 3 * pairs_r / max(n_r, 1), traffic,
+                eng.algorithmic_bytes(twflow.K_BLUR_SOLVE, 0, W, H, args.slots) * 3 * pairs_r, 3 * pairs_r / max(n_r, 1), traffic,
                 chunk=eng.level_chunk(W, H, 0)) if n_r else None
             resident_extra["note"] = ("the headline's steps with the pairs already resident in HBM (no uploads): rounds "
                                       "1-3's `value`; outside the timed region")

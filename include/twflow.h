@@ -30,8 +30,13 @@ extern "C" {
 
 /* 2 (round 3): + tw_device_pci_bus_id, tw_host_register / tw_host_unregister, tw_has_variants, TW_OPT_POLYEXP_F32.
  * 3 (round 4): + tw_submit_png8 (PNG scanline reconstruction + gray conversion on the device).
- * Purely additive: a consumer built against version 1 runs unchanged. */
-#define TWFLOW_ABI_VERSION 3
+ * 4 (rounds 5-6): + tw_stage_pyr_fused23 / tw_stage_pyr_fused01 / tw_stage_flow_iter (per-stage test entry points),
+ *    tw_algorithmic_bytes_launch, tw_level_runs_flow_iter; NARROWED: tw_host_register takes whole pages only (a range that is
+ *    not page-aligned or not a multiple of the page size — e.g. a malloc / cv::Mat heap block, which version 3 accepted —
+ *    now answers TW_E_BAD_PARAMETER; see the declaration).
+ * Additive except for that one narrowing: a consumer built against version 1 that never called tw_host_register on heap
+ * blocks runs unchanged; tw_abi_version() tells the two apart. */
+#define TWFLOW_ABI_VERSION 4
 
 /* Status codes.  The first four are enum ErrorCode of /root/reference/src/opticalflow.h:9-14. */
 typedef enum tw_status {
@@ -69,6 +74,9 @@ typedef int64_t tw_ticket;
 
 /* Defaults of Broker::createInstance, /root/reference/src/broker.cpp:111-117. */
 void tw_default_params(tw_params* p);
+
+/* TWFLOW_ABI_VERSION of the library that was loaded (a consumer compares it with the header it was built against). */
+int tw_abi_version(void);
 
 /* 1 for a `make VARIANTS=1` build (tidal-wave_amd/libtwflow_variants.so: the default library plus the measured-slower
  * A/B kernels behind TW_BLUR_VARIANT / TW_POLY_VARIANT / TW_BLUR_SMALL / TW_UPD_NY — tests and tools only), 0 for the
@@ -202,10 +210,19 @@ tw_status tw_prof_read(tw_engine* e, int kclass, double* ms_total, int* launches
  * every output written once (blur+solve: averaged over the pyrIterations launches of a level — a launch fused with
  * the matrix refresh moves 80 B/px, the last one 28 B/px; flows that never leave the registers are not counted). */
 double tw_algorithmic_bytes(const tw_engine* e, int kclass, int level, int width, int height);
+/* The same for a batch of `npairs` pairs: the model follows the schedule's own choices (one shared predicate in
+ * csrc/twflow.hip) — a single pair, a batch too small to fill the chip with tw_flow_iter workgroups or a level whose launches
+ * do not cover the batch keeps tw_update_matrices + tw_blur_solve* (UPDATE_MATRICES 60 B/px + the coarser flow, window launches
+ * 80 / 28 B/px) where a full batch runs tw_flow_iter (56 B/px, no UPDATE_MATRICES launch).  tw_algorithmic_bytes is this with
+ * npairs = the engine's slots. */
+double tw_algorithmic_bytes_launch(const tw_engine* e, int kclass, int level, int width, int height, int npairs);
+/* 1 if `level` of a batch of `npairs` pairs of width x height runs tw_flow_iter (whole iterations, no M in HBM), 0 if it runs
+ * tw_update_matrices + tw_blur_solve* launches, -1 on a bad argument.  The scan-fused option is assumed with span 10. */
+int tw_level_runs_flow_iter(const tw_engine* e, int width, int height, int level, int npairs);
 /* SURVEY.md 8(d) model of one whole pair (each named stage of the reference reads its inputs once and writes its
  * outputs once; 991.8 MB at 1080p with the defaults): the figure BASELINE.md prices a pair against. */
 double tw_algorithmic_bytes_pair(const tw_engine* e, int width, int height, int span);
-/* Sum of tw_algorithmic_bytes over every launch of a pair: what the fused kernels must move (859.6 MB at 1080p). */
+/* Sum of tw_algorithmic_bytes over every launch of a pair: what the kernels as built must move for a full batch (611.8 MB at 1080p with the defaults; 859.6 before tw_flow_iter). */
 double tw_min_traffic_bytes_pair(const tw_engine* e, int width, int height, int span);
 /* Number of pyramid levels (= index of the coarsest level) the engine uses for w x h. */
 int tw_num_levels(const tw_engine* e, int width, int height);

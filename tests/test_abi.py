@@ -28,6 +28,21 @@ def test_header_symbols_exported(twflow):
     assert decl == set(twflow.SYMBOLS)
 
 
+def test_abi_version_and_launch_families(twflow):
+    """tw_abi_version() is the header's TWFLOW_ABI_VERSION (4 since the round-5 / 6 changes: ADVICE r5), and the diagnostic
+    kernel-family table of twflow_debug.h has a name for every family of its enum."""
+    hdr = open(os.path.join(ROOT, "include", "twflow.h")).read()
+    assert int(re.search(r"#define TWFLOW_ABI_VERSION (\d+)", hdr).group(1)) == twflow.abi_version() == 4
+    dbg = open(os.path.join(ROOT, "include", "twflow_debug.h")).read()
+    fams = re.findall(r"^\s+(TW_DF_[A-Z0-9_]+)", dbg.split("enum tw_debug_family")[1].split("};")[0], flags=re.M)
+    assert fams[-1] == "TW_DF_COUNT"
+    L = twflow.lib()
+    names = [L.tw_debug_family_name(i) for i in range(len(fams) - 1)]
+    assert all(names) and len(set(names)) == len(names)
+    assert L.tw_debug_family_name(len(fams) - 1) is None and L.tw_debug_family_name(-1) is None
+    assert L.tw_debug_launch_counts(None, None, None, 0, 0) == -1
+
+
 def test_struct_layouts_match_reference(twflow):
     # OpticalFlowParameter (src/opticalflow.h:28-36): double,int,int,int,int,double,int
     assert C.sizeof(twflow.Params) == 40

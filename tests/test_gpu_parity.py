@@ -226,32 +226,55 @@ def test_stage_flow_iter_with_fused_upsample(engine, oracle, ph, pw, h, w):
     assert_same(engine.stage_flow_iter(R0, R1, prev=prev), planar(want), "M-free iteration with upsample %dx%d" % (w, h))
 
 
+def _oracle_vectors(oracle, pairs, span, thr, params=None):
+    out = []
+    for a, b in pairs:
+        wx, wy = oracle.farneback(a, b, params) if params is not None else oracle.farneback(a, b)
+        out.append(oracle.span_scan(wx, wy, span, thr))
+    return out
+
+
 def test_pipeline_with_m_free_iterations(twflow, oracle):
-    """TW_MFREE=1: batches of 640x480 and 960x540 pairs run tw_flow_iter at the levels that qualify (>= 320 columns) —
-    flow fields and vectors equal the oracle's, and the default engine's."""
+    """The DEFAULT schedule (no environment switch) on batches large enough to pass its launch-size gate: 24 pairs of 960x540
+    run tw_flow_iter at levels 0 and 1 (level 2 is narrower than 320 columns), 24 pairs of 640x480 at level 0 — and the test
+    ASSERTS it from the engine's launch counters (round 5's version submitted 3-pair batches, which the gate
+    sent to the old kernels).  Threshold 0: every span-grid point with a non-zero flow comes back, so the vectors compare
+    the final flow's float bits at 5 184 / 3 072 points per pair.  Then pyrIterations 1, 2, 4 and 5 WITHOUT the scan-fused
+    option: the iterations' ping-pong between the flow planes and the M0 region must end in the flow planes for odd and even
+    counts alike."""
     import os
     import synth
-    os.environ["TW_MFREE"] = "1"
-    try:
-        for (h, w) in ((480, 640), (540, 960)):
-            pairs = [synth.make_pair(i, h, w) for i in range(3)]
-            with twflow.Engine(0, twflow.default_params(), slots=4) as e:
-                tk = [e.submit(a, b, 10, 1.0) for a, b in pairs]
-                got = [e.wait(t)["vector"] for t in tk]
-                for (a, b), g in zip(pairs, got):
-                    wx, wy = oracle.farneback(a, b)
-                    assert g == oracle.span_scan(wx, wy, 10, 1.0)
-        # non-default iteration counts: the ping-pong must end in the level's flow buffer for 1, 2 and 4 iterations
-        a, b = synth.make_pair(1, 480, 640)
-        for it in (1, 2, 4):
-            p = twflow.default_params(pyrIterations=it)
-            wx, wy = oracle.farneback(a, b, oracle.default_params(pyrIterations=it))
-            with twflow.Engine(0, p, slots=2) as e:
-                t1, t2 = e.submit(a, b, 10, 0.5), e.submit(b, a, 10, 0.5)
-                assert e.wait(t1)["vector"] == oracle.span_scan(wx, wy, 10, 0.5)
-                e.wait(t2)
-    finally:
-        del os.environ["TW_MFREE"]
+    assert "TW_MFREE" not in os.environ
+    for (h, w), fi_levels in (((540, 960), 2), ((480, 640), 1)):
+        distinct = [synth.make_pair(i, h, w) for i in range(4)]
+        want = _oracle_vectors(oracle, distinct, 10, 0.0)
+        with twflow.Engine(0, twflow.default_params(), slots=24) as e:
+            assert [e.level_runs_flow_iter(w, h, k, 24) for k in range(4)] == [k < fi_levels for k in range(4)]
+            assert not any(e.level_runs_flow_iter(w, h, k, 3) for k in range(4))  # (what round 5's test submitted)
+            e.launch_counts(reset=True)
+            tk = [e.submit(*distinct[i % 4], 10, 0.0) for i in range(24)]
+            got = [e.wait(t)["vector"] for t in tk]
+            cnt = e.launch_counts()
+            assert cnt["tw_flow_iter_ups"] == fi_levels and cnt["tw_flow_iter"] == 2 * fi_levels and cnt["tw_flow_iter_zero"] == 0, cnt
+            assert cnt.last_z["tw_flow_iter"] == 24 and cnt.last_z["tw_flow_iter_ups"] == 24, cnt.last_z
+            # the other levels: one first update + three window launches each; nothing else touched M
+            assert cnt["tw_update_matrices"] == 4 - fi_levels, cnt
+            for i, g in enumerate(got):
+                assert len(want[i % 4]) > 1000
+                assert g == want[i % 4], "pair %d of the %dx%d batch" % (i, w, h)
+    a, b = synth.make_pair(1, 480, 640)
+    c, d = synth.make_pair(2, 480, 640)
+    for it in (1, 2, 4, 5):
+        p = twflow.default_params(pyrIterations=it)
+        want = _oracle_vectors(oracle, [(a, b), (c, d)], 10, 0.0, oracle.default_params(pyrIterations=it))
+        with twflow.Engine(0, p, slots=24) as e:
+            e.launch_counts(reset=True)
+            tk = [e.submit(*((a, b) if i % 2 == 0 else (c, d)), 10, 0.0) for i in range(24)]
+            got = [e.wait(t)["vector"] for t in tk]
+            cnt = e.launch_counts()
+            assert cnt["tw_flow_iter_ups"] == 1 and cnt["tw_flow_iter"] == it - 1 and cnt["tw_blur_grid"] == 0, (it, cnt)
+            for i, g in enumerate(got):
+                assert g == want[i % 2], "pyrIterations %d, pair %d" % (it, i)
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -543,12 +566,20 @@ def test_pipeline_with_every_round5_fusion_forced(twflow, oracle):
         for (h, w) in ((480, 640), (482, 646)):
             pairs = [synth.make_pair(i, h, w) for i in range(3)]
             with twflow.Engine(0, twflow.default_params(), slots=4) as e:
+                e.launch_counts(reset=True)
                 tk = [e.submit(a, b, 10, 1.0) for a, b in pairs]
                 got = [e.wait(t)["vector"] for t in tk]
+                cnt = e.launch_counts(reset=True)
+                assert cnt["tw_flow_iter_ups"] == 2 and cnt["tw_flow_iter"] == 4, cnt
+                if (h, w) == (480, 640):  # (646 x 482 halves once, not three times: no tw_pyr_23 for it)
+                    assert cnt["tw_pyr_23"] == 1 and cnt["tw_pyr_k3f"] == 1 and cnt["tw_pyr_k3"] == 0 and cnt["tw_pyr_taps"] == 0, cnt
+                else:
+                    assert cnt["tw_pyr_23"] == 0 and cnt["tw_pyr_taps"] == 2, cnt
                 for (a, b), g in zip(pairs, got):
                     wx, wy = oracle.farneback(a, b)
                     assert g == oracle.span_scan(wx, wy, 10, 1.0)
                 gx, gy, _ = e.calculate_internal(*pairs[1])
+                assert e.launch_counts().flow_iter() == 6  # the batch of one as well (TW_LATENCY_STREAMS=0)
                 wx, wy = oracle.farneback(*pairs[1])
                 assert_same(gx, wx, "flowx %dx%d" % (w, h))
                 assert_same(gy, wy, "flowy %dx%d" % (w, h))
@@ -574,12 +605,17 @@ def test_single_pair_schedule_of_twin_launches(twflow, oracle):
             gx, gy, _ = e.calculate_internal(a, b)
             v = e.diff(a, b, 10, 0.5)["vector"]
             v2 = e.diff(b, a, 10, 0.5)["vector"]   # the same buffers again, the other way round
+            cnt = e.launch_counts()
+            assert cnt.flow_iter() == 0, cnt  # a single pair keeps the tile kernels
+            if not kw and (h, w) in ((1080, 1920), (480, 640)):
+                assert cnt["tw_twin"] >= 3 * 6, cnt  # the twin schedule is what ran: >= 6 two-body launches per pair
         os.environ["TW_LAT_FUSED"] = "0"
         try:
             with twflow.Engine(0, twflow.default_params(**kw), slots=1) as e:
                 hx, hy, _ = e.calculate_internal(a, b)
                 assert e.diff(a, b, 10, 0.5)["vector"] == v
                 assert e.diff(b, a, 10, 0.5)["vector"] == v2
+                assert e.launch_counts()["tw_twin"] == 0
         finally:
             del os.environ["TW_LAT_FUSED"]
         assert_same(gx, hx, "flowx %dx%d %r" % (w, h, kw))
@@ -613,6 +649,9 @@ def test_scan_fused_final_on_top_of_m_free_iterations(twflow, oracle):
                 for (a, b), t in zip(pairs[:2], tk):
                     wx, wy = oracle.farneback(a, b, oracle.default_params(pyrIterations=it))
                     assert e.wait(t)["vector"] == oracle.span_scan(wx, wy, 10, 1.0)
+                cnt = e.launch_counts()
+                assert cnt["tw_blur_grid"] == 7, cnt  # every diff / batch above took the grid kernel for its last iteration
+                assert (cnt.flow_iter() > 0) == (it > 1), (it, cnt)
     finally:
         del os.environ["TW_MFREE"]
         del os.environ["TW_LATENCY_STREAMS"]
@@ -672,14 +711,28 @@ def test_config5_full_size_4k(twflow, oracle):
     import synth
     kw = dict(pyrLevels=5, winSize=50, pyrIterations=5)
     a, b = synth.make_pair(1, 2160, 3840)
-    with twflow.Engine(0, twflow.default_params(**kw), slots=2) as e:
+    with twflow.Engine(0, twflow.default_params(**kw), slots=4) as e:
         assert e.num_levels(3840, 2160) == 5
         r = e.wait(e.submit(a, b))
         gx, gy, _ = e.calculate_internal(a, b)
+        # ... and the BATCH shape bench.py's config5_4k runs (same kernels as the single pair, different
+        # chunking): the pair inside a 3-pair batch, its flow compared at every fourth pixel (span 4, threshold 0: 518 400
+        # grid points, all of those with a non-zero flow come back in scan order with their float bits)
+        e.launch_counts(reset=True)
+        tk = [e.submit(a, b, 4, 0.0), e.submit(b, a, 4, 0.0), e.submit(a, b, 4, 0.0)]
+        batch = [e.wait(t)["vector"] for t in tk]
+        cnt = e.launch_counts()
     wx, wy = oracle.farneback(a, b, oracle.default_params(**kw))
     assert_same(gx, wx, "4K config-5 flowx")
     assert_same(gy, wy, "4K config-5 flowy")
     assert r["vector"] == oracle.span_scan(wx, wy, 10, 5.0)
+    # the 51-tap window kernels ran on the whole batch (wide levels tw_blur_solve4y, narrow ones tw_blur_solve8), never
+    # tw_flow_iter (its LDS ring does not hold a 51-tap window)
+    assert cnt["tw_blur_solve4y"] > 0 and cnt.last_z["tw_blur_solve4y"] == 3 and cnt["tw_blur_solve8"] > 0 and cnt.flow_iter() == 0, cnt
+    want = oracle.span_scan(wx, wy, 4, 0.0)
+    assert len(want) > 400000
+    assert batch[0] == want, "4K pair inside a 3-pair batch"
+    assert batch[2] == want, "... and its second copy in the same batch"
 
 
 @pytest.mark.parametrize("kw", [dict(flags=0), dict(flags=0, winSize=13, pyrIterations=2), dict(flags=4), dict(flags=260)])
@@ -1068,22 +1121,62 @@ def test_8k_pair_properties_and_size_limit(twflow):
         assert ei.value.code == twflow.TW_E_UNSUPPORTED
 
 
+def _process_memory():
+    """Where the process's memory is, from three independent books: the kernel's (smaps_rollup), glibc malloc's (mallinfo2,
+    all arenas: what the library and the HIP runtime hold through malloc / new) and nothing of Python's own."""
+    import ctypes
+
+    class MallInfo2(ctypes.Structure):
+        _fields_ = [(n, ctypes.c_size_t) for n in ("arena", "ordblks", "smblks", "hblks", "hblkhd", "usmblks", "fsmblks",
+                                                    "uordblks", "fordblks", "keepcost")]
+    out = {}
+    try:
+        for line in open("/proc/self/smaps_rollup"):
+            k, _, v = line.partition(":")
+            if k in ("Rss", "Anonymous", "AnonHugePages", "Shared_Clean", "Shared_Dirty", "Private_Clean", "Private_Dirty", "Locked"):
+                out[k] = int(v.split()[0]) / 1e3  # MB
+    except OSError:
+        out["Rss"] = int(open("/proc/self/statm").read().split()[1]) * 4096 / 1e6
+    try:
+        libc = ctypes.CDLL(None)
+        libc.mallinfo2.restype = MallInfo2
+        mi = libc.mallinfo2()
+        out["malloc_in_use"] = (mi.uordblks + mi.hblkhd) / 1e6   # bytes handed out and not freed (heap + mmapped chunks)
+        out["malloc_from_os"] = (mi.arena + mi.hblkhd) / 1e6     # what malloc holds from the system (grows in steps, rarely shrinks)
+    except (AttributeError, OSError):
+        pass
+    return out
+
+
 def test_host_uploads_do_not_grow_the_process(twflow):
-    """A service uploads host images for hours: 12 800 pinned and 12 800 pageable 480x270 pairs must not grow the
-    resident set (a 300 000-pair soak found ~1 KB per uploaded image left behind in the runtime's copy-stream
-    bookkeeping until the host synchronises that stream)."""
+    """A service uploads host images for hours: 12 800 pinned and 12 800 pageable 480x270 pairs must not leak (a 300 000-pair
+    soak found ~1 KB per uploaded image left behind in the runtime's copy-stream bookkeeping until the host synchronises that
+    stream: 10 MB over this test's measured span).
+
+    Round 5 saw this test fail ONCE inside the full suite with a +190 MB step of the resident set (never alone) and loosened
+    it; VERDICT r5 #3 asked for the cause instead.  The resident set is the wrong book to assert tightly on: it also moves when
+    the kernel's khugepaged collapses a sparse heap into huge pages, when glibc takes a fresh 64 MB arena for a runtime thread
+    or re-touches pages it had trimmed after earlier tests' frees — none of which is a leak.  So the test now keeps three
+    books per iteration and asserts on the exact ones:
+      1. the LIBRARY's own accounting (tw_debug_memory: device bytes, page-locked bytes, plans, page-lock table, pooled
+         events) must not move at all once the first batches have sized everything;
+      2. glibc malloc's bytes IN USE (mallinfo2 over all arenas: every new / malloc of the library and of the HIP runtime,
+         whatever the allocator then does with the pages) must stay within 2 MB — the 1 KB-per-image leak is 10 MB here;
+      3. the resident set, coarsely (< 256 MB), with the whole series written to gpurun_out/r06_leak_trace.json so that a
+         step, if one shows again, is attributed from the record of that one run (AnonHugePages vs malloc_from_os vs
+         neither = driver mappings) instead of being hunted by re-running."""
+    import json
+    import os
     import synth
 
-    def rss_mb():
-        return int(open("/proc/self/statm").read().split()[1]) * 4096 / 1e6
-
     a, b = synth.make_pair(2, 270, 480)
+    trace = []
     with twflow.Engine(0, twflow.default_params(), slots=64) as e:
         pa, pb = e.host_array(a.shape), e.host_array(a.shape)
         pa[:] = a
         pb[:] = b
         first = None
-        for src in ((pa, pb), (a, b)):
+        for name, src in (("pinned", (pa, pb)), ("pageable", (a, b))):
             for it in range(200):
                 tk = [e.submit(src[0], src[1]) for _ in range(64)]
                 hits = [e.wait_count(t)[0] for t in tk]
@@ -1091,15 +1184,24 @@ def test_host_uploads_do_not_grow_the_process(twflow):
                 if first is None:
                     first = hits[0]
                 assert hits[0] == first
-                if it == 40:
-                    base = rss_mb()
-                if it == 120:
-                    mid = rss_mb()
-            # a leak grows in BOTH halves (1 KB per image = 5 MB per half); a one-off step of the allocator / the runtime's
-            # pools in one half (seen once in the full suite: +190 MB, never alone) is not one
-            end = rss_mb()
-            assert min(mid - base, end - mid) < 4.0, \
-                "resident set grew by %.1f + %.1f MB over 2 x 5 120 pairs" % (mid - base, end - mid)
+                if it % 10 == 0 or it == 199:
+                    trace.append(dict(half=name, it=it, engine=e.memory(), **_process_memory()))
+    try:
+        out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "r06_leak_trace.json"), "w") as f:
+            json.dump(trace, f, indent=0)
+    except OSError:
+        pass
+    for name in ("pinned", "pageable"):
+        rows = [r for r in trace if r["half"] == name and r["it"] >= 40]
+        base, end = rows[0], rows[-1]
+        assert all(r["engine"] == base["engine"] for r in rows), \
+            "%s: the library's own accounting moved: %r -> %r" % (name, base["engine"], end["engine"])
+        if "malloc_in_use" in base:
+            grew = end["malloc_in_use"] - base["malloc_in_use"]
+            assert grew < 2.0, "%s: malloc bytes in use grew by %.2f MB over 10 240 pairs (%r -> %r)" % (name, grew, base, end)
+        assert end["Rss"] - base["Rss"] < 256.0, "%s: resident set %r -> %r" % (name, base, end)
 
 
 def test_out_of_memory_is_reported_and_the_engine_recovers(twflow, oracle, monkeypatch):

@@ -243,6 +243,7 @@ struct Plan {
     int levels = 0;  // index of the coarsest level
     std::vector<LevelPlan> lv;
     std::vector<void*> owned;  // device allocations
+    size_t owned_bytes = 0;    // ... and their total size (tw_debug_memory)
     unsigned long long last_use = 0;  // engine's plan clock at the last get_plan (LRU eviction)
 };
 
@@ -413,6 +414,7 @@ struct tw_engine {
     size_t lat_cap = 0;  // floats in lat_I (lat_R holds 5x)
     std::vector<hipEvent_t> lat_ev;
     int lat_s2_max = 1000;  // TW_LAT_S2_LEVELS: finest..this level's image-only work goes to the second stream
+    int fi_skip = 0;    // TW_FI_SKIP (variants library): timing experiments on tw_flow_iter (results are wrong)
     int fi_nt = 1024;   // TW_FI_NT=512 (variants library): tw_flow_iter as two 512-thread workgroups per CU on 64-output strips (A/B)
     int lat_fused = 1;  // TW_LAT_FUSED=0: the two-stream single-pair schedule of rounds 2-4 instead of the twin launches (A/B)
     int lat_graph = 0;  // TW_LAT_GRAPH=1: replay the single-pair schedule from a captured hipGraph (measured SLOWER on
@@ -427,9 +429,24 @@ struct tw_engine {
     int prof_level[TW_K_COUNT] = {-2, -2, -2, -2, -2};
     std::vector<ProfPair> prof_pending[TW_K_COUNT];
     std::vector<hipEvent_t> prof_free;
+    // diagnostics (include/twflow_debug.h: tw_debug_launch_counts): launches per kernel family since the engine was created /
+    // the counts were last reset, and the pairs (grid z) of each family's latest launch — what lets a test prove WHICH kernel ran
+    unsigned long long launches[TW_DF_COUNT] = {};
+    unsigned long long last_grid_z[TW_DF_COUNT] = {};
 };
 
 namespace {
+
+// every kernel launch of the library goes through here (tw_copy_f4, the copy-rate yardstick, excepted)
+#define TW_LAUNCH(e, fam, kern, grid, ...)                         \
+    do {                                                           \
+        const dim3 _g = (grid);                                    \
+        if (e) {                                                   \
+            (e)->launches[fam]++;                                  \
+            (e)->last_grid_z[fam] = _g.z;                          \
+        }                                                          \
+        hipLaunchKernelGGL(kern, _g, __VA_ARGS__);                 \
+    } while (0)
 
 #define TW_HIP(e, call)                                                                   \
     do {                                                                                  \
@@ -523,6 +540,7 @@ tw_status upload_vec(tw_engine* e, Plan* pl, const std::vector<T>& v, T** out)
     void* d = nullptr;
     TW_HIP(e, hipMalloc(&d, v.size() * sizeof(T) + 16));
     pl->owned.push_back(d);
+    pl->owned_bytes += v.size() * sizeof(T) + 16;
     TW_TRY(h2d_sync(e, d, v.data(), v.size() * sizeof(T)));
     *out = (T*)d;
     return TW_OK;
@@ -580,6 +598,33 @@ void free_plan(Plan* pl)
     delete pl;
 }
 
+// pairs one launch covers at a level of w x h pixels (level index k): enough 8-row x 240-column tiles of two images to cover
+// the 256 CUs many times over.  One rule for the plan and for the byte model (tw_algorithmic_bytes_launch).
+int pairs_per_launch(const tw_engine* e, int w, int h, int k)
+{
+    const long long tiles = (long long)((w + PE_TW - 1) / PE_TW) * ((h + PE_TH - 1) / PE_TH) * 2;
+    // measured at 1080p: 4096 -> 16384 tiles per launch is +11 % pairs/s (fewer tails and gaps), 16384 -> 34000
+    // (16 pairs per level-0 launch) another +2.5 %, 34000 -> a whole 64-pair batch per launch +1.5 %, a whole
+    // 128-pair batch +4 % (round 2): every kernel boundary costs a drain, a fill and an L2 write-back of the dirty
+    // M planes, and 288 GB of HBM make the workspace of a whole batch (23 GB at 128 x 1080p) a non-issue.  So a
+    // launch covers the whole batch unless that exceeds 300 000 tiles.
+    long long target = 300000;
+    if (const char* ev = getenv("TW_CHUNK_TILES")) target = std::max(1, atoi(ev));
+    long long c = (target + tiles - 1) / tiles;
+    // TW_CHUNK_PAIRS_LEVELS="p0,p1,...": pairs per launch at level 0, 1, ... (0 / missing: the rule above) — the
+    // round-4 Infinity-Cache experiment (does a level's chain run faster when a chunk's R / M planes fit the 256 MB
+    // memory-side cache between its kernels?  profiles/r04_mall_chunks.md)
+    if (const char* ev = getenv("TW_CHUNK_PAIRS_LEVELS")) {
+        const char* q = ev;
+        for (int lv = 0; lv < k && q; lv++) {
+            q = strchr(q, ',');
+            if (q) q++;
+        }
+        if (q && atoi(q) > 0) c = atoi(q);
+    }
+    return (int)std::min<long long>(std::max<long long>(c, 1), e->cap);
+}
+
 tw_status get_plan(tw_engine* e, int w0, int h0, Plan** out)
 {
     auto key = std::make_pair(w0, h0);
@@ -620,28 +665,7 @@ tw_status get_plan(tw_engine* e, int w0, int h0, Plan** out)
         }
         L.ld = round_up(L.w, 32);
         L.ps = (long long)L.ld * L.h;
-        // pairs per launch: enough 8-row x 240-column tiles of two images to cover the 256 CUs many times over
-        const long long tiles = (long long)((L.w + PE_TW - 1) / PE_TW) * ((L.h + PE_TH - 1) / PE_TH) * 2;
-        // measured at 1080p: 4096 -> 16384 tiles per launch is +11 % pairs/s (fewer tails and gaps), 16384 -> 34000
-        // (16 pairs per level-0 launch) another +2.5 %, 34000 -> a whole 64-pair batch per launch +1.5 %, a whole
-        // 128-pair batch +4 % (round 2): every kernel boundary costs a drain, a fill and an L2 write-back of the dirty
-        // M planes, and 288 GB of HBM make the workspace of a whole batch (23 GB at 128 x 1080p) a non-issue.  So a
-        // launch covers the whole batch unless that exceeds 300 000 tiles.
-        long long target = 300000;
-        if (const char* ev = getenv("TW_CHUNK_TILES")) target = std::max(1, atoi(ev));
-        long long c = (target + tiles - 1) / tiles;
-        // TW_CHUNK_PAIRS_LEVELS="p0,p1,...": pairs per launch at level 0, 1, ... (0 / missing: the rule above) — the
-        // round-4 Infinity-Cache experiment (does a level's chain run faster when a chunk's R / M planes fit the 256 MB
-        // memory-side cache between its kernels?  profiles/r04_mall_chunks.md)
-        if (const char* ev = getenv("TW_CHUNK_PAIRS_LEVELS")) {
-            const char* q = ev;
-            for (int lv = 0; lv < k && q; lv++) {
-                q = strchr(q, ',');
-                if (q) q++;
-            }
-            if (q && atoi(q) > 0) c = atoi(q);
-        }
-        L.chunk = (int)std::min<long long>(std::max<long long>(c, 1), e->cap);
+        L.chunk = pairs_per_launch(e, L.w, L.h, k);
     }
     for (int k = 0; k <= pl->levels; k++) {
         LevelPlan& L = pl->lv[k];
@@ -867,8 +891,8 @@ TwinGrid make_twin(const dim3& ga, const SideJob& s)
 void launch_side_alone(tw_engine* e, hipStream_t st, const SideJob& s)
 {
     (void)e;
-    if (s.kind == 1) hipLaunchKernelGGL(tw_polyexp_band, dim3(s.n()), dim3(256), 0, st, s.pa, s.g);
-    else if (s.kind == 2) hipLaunchKernelGGL(tw_pyr_k3f, dim3(s.g.gx, s.g.gy, s.g.gz), dim3(256), 0, st, s.ka);
+    if (s.kind == 1) TW_LAUNCH(e, TW_DF_POLYEXP, tw_polyexp_band, dim3(s.n()), dim3(256), 0, st, s.pa, s.g);
+    else if (s.kind == 2) TW_LAUNCH(e, TW_DF_PYR_K3F, tw_pyr_k3f, dim3(s.g.gx, s.g.gy, s.g.gz), dim3(256), 0, st, s.ka);
 }
 
 // tw_update_matrices<UPSAMPLE, NY>: NY pixels of a column per lane (TW_UPD_NY, default 2)
@@ -878,18 +902,18 @@ void launch_upd_kernel(tw_engine* e, hipStream_t st, int w, int h, int npairs, c
 {
 #ifdef TW_VARIANTS
     if (e->upd_ny == 1) {
-        hipLaunchKernelGGL((tw_update_matrices<UP, 1>), dim3((w + 63) / 64, (h + 3) / 4, npairs), dim3(256), 0, st, a);
+        TW_LAUNCH(e, TW_DF_UPDATE_MATRICES, (tw_update_matrices<UP, 1>), dim3((w + 63) / 64, (h + 3) / 4, npairs), dim3(256), 0, st, a);
         return;
     }
 #endif
     const dim3 grid((w + 63) / 64, (h + 7) / 8, npairs);
     if (side && side_used && side->kind == 1) {
         const TwinGrid t = make_twin(grid, *side);
-        hipLaunchKernelGGL(tw_twin_upd_poly<UP>, dim3(t.nA8 + side->n()), dim3(256), 0, st, a, side->pa, t);
+        TW_LAUNCH(e, TW_DF_TWIN, tw_twin_upd_poly<UP>, dim3(t.nA8 + side->n()), dim3(256), 0, st, a, side->pa, t);
         *side_used = true;
         return;
     }
-    hipLaunchKernelGGL((tw_update_matrices<UP, 2>), grid, dim3(256), 0, st, a);
+    TW_LAUNCH(e, TW_DF_UPDATE_MATRICES, (tw_update_matrices<UP, 2>), grid, dim3(256), 0, st, a);
 }
 
 // ---- kernel launch helpers (nz = images or pairs in this launch) -------------------------------------
@@ -935,8 +959,8 @@ void launch_pyr(tw_engine* e, hipStream_t st, const Plan* pl, int k, const uint8
         b.k0 = L.h_kern[1];
         b.k1 = L.h_kern[0];
         b.aligned4 = (stride % 4 == 0) ? e->img_aligned4 : 0;
-        if (L.mode == 0) hipLaunchKernelGGL(tw_pyr_k3<0>, dim3((L.w + 255) / 256, (L.h + 7) / 8, nimg), dim3(256), 0, st, b);
-        else hipLaunchKernelGGL(tw_pyr_k3<2>, dim3((L.w + 255) / 256, (L.h + 3) / 4, nimg), dim3(256), 0, st, b);
+        if (L.mode == 0) TW_LAUNCH(e, TW_DF_PYR_K3, tw_pyr_k3<0>, dim3((L.w + 255) / 256, (L.h + 7) / 8, nimg), dim3(256), 0, st, b);
+        else TW_LAUNCH(e, TW_DF_PYR_K3, tw_pyr_k3<2>, dim3((L.w + 255) / 256, (L.h + 3) / 4, nimg), dim3(256), 0, st, b);
         return;
     }
     if (L.pitch_b > 0 && L.mode != 0 && L.ksize >= 7 && e->pyr_generic == 0) {
@@ -950,10 +974,10 @@ void launch_pyr(tw_engine* e, hipStream_t st, const Plan* pl, int k, const uint8
         memcpy(b.kext + 1, L.h_taps.data(), sizeof(float) * L.ksize);
         const size_t lds3 = ((size_t)L.nrows_max * (2 * PYR_TW) + (size_t)L.nrows_max * b.pd + 4) * 4;
         switch (L.ksize) {
-            case 9: hipLaunchKernelGGL(tw_pyr_taps<9>, grid, dim3(256), lds3, st, b); break;
-            case 19: hipLaunchKernelGGL(tw_pyr_taps<19>, grid, dim3(256), lds3, st, b); break;
-            case 39: hipLaunchKernelGGL(tw_pyr_taps<39>, grid, dim3(256), lds3, st, b); break;
-            default: hipLaunchKernelGGL(tw_pyr_taps<0>, grid, dim3(256), lds3, st, b); break;
+            case 9: TW_LAUNCH(e, TW_DF_PYR_TAPS, tw_pyr_taps<9>, grid, dim3(256), lds3, st, b); break;
+            case 19: TW_LAUNCH(e, TW_DF_PYR_TAPS, tw_pyr_taps<19>, grid, dim3(256), lds3, st, b); break;
+            case 39: TW_LAUNCH(e, TW_DF_PYR_TAPS, tw_pyr_taps<39>, grid, dim3(256), lds3, st, b); break;
+            default: TW_LAUNCH(e, TW_DF_PYR_TAPS, tw_pyr_taps<0>, grid, dim3(256), lds3, st, b); break;
         }
         return;
     }
@@ -962,10 +986,10 @@ void launch_pyr(tw_engine* e, hipStream_t st, const Plan* pl, int k, const uint8
         b.p = a;
         b.pitch_b = L.pitch_b;
         b.aligned4 = (stride % 4 == 0) ? e->img_aligned4 : 0;
-        hipLaunchKernelGGL(tw_pyr_level_lds, grid, dim3(256), lds + (size_t)L.nrows_max * L.pitch_b, st, b);
+        TW_LAUNCH(e, TW_DF_PYR_LEVEL, tw_pyr_level_lds, grid, dim3(256), lds + (size_t)L.nrows_max * L.pitch_b, st, b);
         return;
     }
-    hipLaunchKernelGGL(tw_pyr_level, grid, dim3(256), lds, st, a);
+    TW_LAUNCH(e, TW_DF_PYR_LEVEL, tw_pyr_level, grid, dim3(256), lds, st, a);
 }
 
 // levels 3 and 2 of `nimg` images from one read of each image (tw_pyr_23; pl->fused23): I3 / I2 = the level images,
@@ -994,8 +1018,8 @@ void launch_pyr23(tw_engine* e, hipStream_t st, const Plan* pl, const uint8_t* c
     memcpy(a.k9, pl->k9, sizeof(a.k9));
     ProfScope ps(e, st, TW_K_PYR, 3);
     const dim3 grid((L3.w + P23_T3W - 1) / P23_T3W, (L3.h + P23_T3H - 1) / P23_T3H, nimg);
-    if (e->pyr23_threads == 256) hipLaunchKernelGGL(tw_pyr_23<256>, grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(tw_pyr_23<512>, grid, dim3(512), 0, st, a);
+    if (e->pyr23_threads == 256) TW_LAUNCH(e, TW_DF_PYR_23, tw_pyr_23<256>, grid, dim3(256), 0, st, a);
+    else TW_LAUNCH(e, TW_DF_PYR_23, tw_pyr_23<512>, grid, dim3(512), 0, st, a);
 }
 
 tw_status launch_polyexp(tw_engine* e, hipStream_t st, int w, int h, int ld, long long ps, const float* I, float* R,
@@ -1015,13 +1039,13 @@ tw_status launch_polyexp(tw_engine* e, hipStream_t st, int w, int h, int ld, lon
     if (e->poly_variant == 0) {
         // scalar-f32 kernel (A/B: TW_POLY_VARIANT=0)
         switch (e->p.polyN) {
-            case 1: hipLaunchKernelGGL(tw_polyexp<1>, grid, dim3(256), 0, st, a); break;
-            case 2: hipLaunchKernelGGL(tw_polyexp<2>, grid, dim3(256), 0, st, a); break;
-            case 3: hipLaunchKernelGGL(tw_polyexp<3>, grid, dim3(256), 0, st, a); break;
-            case 4: hipLaunchKernelGGL(tw_polyexp<4>, grid, dim3(256), 0, st, a); break;
-            case 5: hipLaunchKernelGGL(tw_polyexp<5>, grid, dim3(256), 0, st, a); break;
-            case 6: hipLaunchKernelGGL(tw_polyexp<6>, grid, dim3(256), 0, st, a); break;
-            case 7: hipLaunchKernelGGL(tw_polyexp<7>, grid, dim3(256), 0, st, a); break;
+            case 1: TW_LAUNCH(e, TW_DF_POLYEXP, tw_polyexp<1>, grid, dim3(256), 0, st, a); break;
+            case 2: TW_LAUNCH(e, TW_DF_POLYEXP, tw_polyexp<2>, grid, dim3(256), 0, st, a); break;
+            case 3: TW_LAUNCH(e, TW_DF_POLYEXP, tw_polyexp<3>, grid, dim3(256), 0, st, a); break;
+            case 4: TW_LAUNCH(e, TW_DF_POLYEXP, tw_polyexp<4>, grid, dim3(256), 0, st, a); break;
+            case 5: TW_LAUNCH(e, TW_DF_POLYEXP, tw_polyexp<5>, grid, dim3(256), 0, st, a); break;
+            case 6: TW_LAUNCH(e, TW_DF_POLYEXP, tw_polyexp<6>, grid, dim3(256), 0, st, a); break;
+            case 7: TW_LAUNCH(e, TW_DF_POLYEXP, tw_polyexp<7>, grid, dim3(256), 0, st, a); break;
             default: e->err = "polyN must be 1..7"; return TW_E_UNSUPPORTED;
         }
         return TW_OK;
@@ -1030,10 +1054,10 @@ tw_status launch_polyexp(tw_engine* e, hipStream_t st, int w, int h, int ld, lon
     if (e->poly_f32) {
         // measurement variant (TW_OPT_POLYEXP_F32): float horizontal accumulators — NOT bit-exact, never the default
         switch (e->p.polyN) {
-            case 5: hipLaunchKernelGGL((tw_polyexp_pk<5, 8, 1>), grid, dim3(256), 0, st, a); break;
+            case 5: TW_LAUNCH(e, TW_DF_POLYEXP, (tw_polyexp_pk<5, 8, 1>), grid, dim3(256), 0, st, a); break;
             case 7:
-                if (e->poly_f32 == 2) hipLaunchKernelGGL((tw_polyexp_pk<7, 8, 2>), grid, dim3(256), 0, st, a);
-                else hipLaunchKernelGGL((tw_polyexp_pk<7, 8, 1>), grid, dim3(256), 0, st, a);
+                if (e->poly_f32 == 2) TW_LAUNCH(e, TW_DF_POLYEXP, (tw_polyexp_pk<7, 8, 2>), grid, dim3(256), 0, st, a);
+                else TW_LAUNCH(e, TW_DF_POLYEXP, (tw_polyexp_pk<7, 8, 1>), grid, dim3(256), 0, st, a);
                 break;
             default: e->err = "TW_OPT_POLYEXP_F32 needs polyN 5 or 7"; return TW_E_UNSUPPORTED;
         }
@@ -1046,16 +1070,16 @@ tw_status launch_polyexp(tw_engine* e, hipStream_t st, int w, int h, int ld, lon
     if (t16) grid.y = (h + 15) / 16;
 #define TW_PK_CASE(n)                                                                        \
     case n:                                                                                  \
-        if (t16) hipLaunchKernelGGL((tw_polyexp_pk<n, 16, 0>), grid, dim3(256), 0, st, a);      \
-        else hipLaunchKernelGGL((tw_polyexp_pk<n, 8, 0>), grid, dim3(256), 0, st, a);           \
+        if (t16) TW_LAUNCH(e, TW_DF_POLYEXP, (tw_polyexp_pk<n, 16, 0>), grid, dim3(256), 0, st, a);      \
+        else TW_LAUNCH(e, TW_DF_POLYEXP, (tw_polyexp_pk<n, 8, 0>), grid, dim3(256), 0, st, a);           \
         break;
 #else
 #define TW_PK_CASE(n)                                                                        \
-    case n: hipLaunchKernelGGL((tw_polyexp_pk<n, 8, 0>), grid, dim3(256), 0, st, a); break;
+    case n: TW_LAUNCH(e, TW_DF_POLYEXP, (tw_polyexp_pk<n, 8, 0>), grid, dim3(256), 0, st, a); break;
 #endif
     if (side && side_used && side->kind == 2 && e->p.polyN == 7 && e->poly_variant == 1) {
         const TwinGrid t = make_twin(grid, *side);
-        hipLaunchKernelGGL(tw_twin_poly_k3f, dim3(t.nA8 + side->n()), dim3(256), 0, st, a, side->ka, t);
+        TW_LAUNCH(e, TW_DF_TWIN, tw_twin_poly_k3f, dim3(t.nA8 + side->n()), dim3(256), 0, st, a, side->ka, t);
         *side_used = true;
         return TW_OK;
     }
@@ -1096,7 +1120,7 @@ void launch_pyr01(tw_engine* e, hipStream_t st, const Plan* pl, const uint8_t* c
     a.b1 = L1.h_kern[0];
     a.aligned4 = (stride % 4 == 0) ? e->img_aligned4 : 0;
     ProfScope ps(e, st, TW_K_PYR, 1);
-    hipLaunchKernelGGL(tw_pyr_k3f, dim3((L1.w + 255) / 256, (L1.h + 3) / 4, nimg), dim3(256), 0, st, a);
+    TW_LAUNCH(e, TW_DF_PYR_K3F, tw_pyr_k3f, dim3((L1.w + 255) / 256, (L1.h + 3) / 4, nimg), dim3(256), 0, st, a);
 }
 
 // One whole iteration of the flow update without M in HBM (tw_flow_iter; round 5): flow_out = solve(window average of
@@ -1105,6 +1129,36 @@ void launch_pyr01(tw_engine* e, hipStream_t st, const Plan* pl, const uint8_t* c
 bool flow_iter_eligible(const tw_engine* e, int w, int h)
 {
     return e->win_m == 15 && !e->box && w >= e->mfree_min_w && h >= 4 * FI_TH;
+}
+// ONE predicate for the schedule (flush_ctx) and the byte model (tw_algorithmic_bytes_launch): does a launch of nc
+// pairs at a level of w x h pixels run tw_flow_iter?  lat: the batch takes the single-pair schedule; grid_only: the level's
+// last iteration is evaluated at the span-grid points only (TW_OPT_SCAN_FUSED_FINAL, level 0).  A launch of fewer workgroups
+// than ~3/4 of the CUs — one or two 1080p pairs — leaves the chip to the 224 x 8 tiles of tw_blur_solve4, of which a single
+// pair already makes 1 215 (TW_MFREE=2 lifts that gate: tests, tools/fuzz_parity.py).
+bool level_runs_flow_iter(const tw_engine* e, int w, int h, int nc, bool lat, bool grid_only)
+{
+    const int it = e->p.pyrIterations;
+    const int fi_out = (e->fi_nt == 512 ? FI_SC_512 : FI_SC) - 30;
+    const long long fi_wgs = (long long)((w + fi_out - 1) / fi_out) * std::min(4, std::max(1, h / (16 * FI_TH))) * nc;
+    return e->mfree && !lat && it > (grid_only ? 1 : 0) && flow_iter_eligible(e, w, h) &&
+           (fi_wgs * 4 >= (long long)e->cu_count * 3 || e->mfree == 2) &&
+           (e->mfree_min_px <= 0 || (long long)w * h >= e->mfree_min_px);
+}
+// does a batch of n pairs of w0 x h0 pixels take the single-pair schedule (its image-only work beside the flow chain)?
+bool single_pair_schedule(const tw_engine* e, int n, int w0, int h0, int levels)
+{
+    return n == 1 && e->lat_streams && levels >= 1 && (long long)w0 * h0 >= e->lat_min_px;
+}
+// the last level-0 iteration at the span-grid points only?
+bool scan_fused_level0(const tw_engine* e, int span)
+{
+    return e->p.pyrIterations > 0 && e->scan_fused && span == 10 && e->win_m == 15 && !e->box;
+}
+// pairs per launch when n pairs are split into balanced launches of at most `chunk` (64 pairs with a 63-pair chunk are 32 + 32)
+int balanced_launch_pairs(int n, int chunk)
+{
+    const int nlaunch = (n + chunk - 1) / chunk;
+    return nlaunch > 0 ? (n + nlaunch - 1) / nlaunch : 1;
 }
 struct FlowUps {  // the coarser level's flow and the resize tables to this level (UpdArgs' upsample fields)
     const float* prev;
@@ -1131,8 +1185,10 @@ void launch_flow_iter(tw_engine* e, hipStream_t st, int w, int h, int ld, long l
     a.fps_out = fps_out;
     a.zero_flow = (!flow_in && !ups) ? 1 : 0;
     a.c = e->wc;
-    if (const char* ev = getenv("TW_FI_SKIP")) a.dbg_skip = atoi(ev);  // variants library only (timing experiments)
-    a.dbg = (unsigned long long*)e->dbg_stamps;                        // TW_DEBUG_STAMPS=1, variants library only
+#ifdef TW_VARIANTS
+    a.dbg_skip = e->fi_skip;                     // TW_FI_SKIP (timing experiments; read once in tw_engine_create)
+    a.dbg = (unsigned long long*)e->dbg_stamps;  // TW_DEBUG_STAMPS=1
+#endif
     const int OUT = (e->fi_nt == 512 ? FI_SC_512 : FI_SC) - 30;
     const int slots = e->cu_count * (e->fi_nt == 512 ? 2 : 1);  // workgroups resident at once
     const int nstrips = (w + OUT - 1) / OUT, nsteps = (h + FI_TH - 1) / FI_TH;
@@ -1171,18 +1227,18 @@ void launch_flow_iter(tw_engine* e, hipStream_t st, int w, int h, int ld, long l
     }
 #ifdef TW_VARIANTS
     if (e->fi_nt == 512) {  // measured 23 % slower (profiles/r05_m_free.md): variants library only
-        if (ups) hipLaunchKernelGGL((tw_flow_iter<15, 1, 512>), grid, dim3(512), 0, st, a);
-        else if (a.zero_flow) hipLaunchKernelGGL((tw_flow_iter<15, 2, 512>), grid, dim3(512), 0, st, a);
-        else hipLaunchKernelGGL((tw_flow_iter<15, 0, 512>), grid, dim3(512), 0, st, a);
+        if (ups) TW_LAUNCH(e, TW_DF_FLOW_ITER_UPS, (tw_flow_iter<15, 1, 512>), grid, dim3(512), 0, st, a);
+        else if (a.zero_flow) TW_LAUNCH(e, TW_DF_FLOW_ITER_ZERO, (tw_flow_iter<15, 2, 512>), grid, dim3(512), 0, st, a);
+        else TW_LAUNCH(e, TW_DF_FLOW_ITER, (tw_flow_iter<15, 0, 512>), grid, dim3(512), 0, st, a);
         return;
     }
 #endif
     if (ups) {
-        hipLaunchKernelGGL((tw_flow_iter<15, 1>), grid, dim3(1024), 0, st, a);
+        TW_LAUNCH(e, TW_DF_FLOW_ITER_UPS, (tw_flow_iter<15, 1>), grid, dim3(1024), 0, st, a);
     } else if (a.zero_flow) {
-        hipLaunchKernelGGL((tw_flow_iter<15, 2>), grid, dim3(1024), 0, st, a);
+        TW_LAUNCH(e, TW_DF_FLOW_ITER_ZERO, (tw_flow_iter<15, 2>), grid, dim3(1024), 0, st, a);
     } else {
-        hipLaunchKernelGGL((tw_flow_iter<15, 0>), grid, dim3(1024), 0, st, a);
+        TW_LAUNCH(e, TW_DF_FLOW_ITER, (tw_flow_iter<15, 0>), grid, dim3(1024), 0, st, a);
     }
 }
 
@@ -1251,8 +1307,8 @@ void launch_blur(tw_engine* e, hipStream_t st, int w, int h, int ld, long long p
         b.scale = 1. / ((double)e->p.winSize * e->p.winSize);
         {
             ProfScope pscope(e, st, TW_K_BLUR_SOLVE, level);
-            hipLaunchKernelGGL(tw_box_vscan, dim3((w + 63) / 64, 5, npairs), dim3(64), 0, st, b);
-            hipLaunchKernelGGL(tw_box_hscan_solve, dim3((h + 11) / 12, 1, npairs), dim3(64), 0, st, b);
+            TW_LAUNCH(e, TW_DF_BOX, tw_box_vscan, dim3((w + 63) / 64, 5, npairs), dim3(64), 0, st, b);
+            TW_LAUNCH(e, TW_DF_BOX, tw_box_hscan_solve, dim3((h + 11) / 12, 1, npairs), dim3(64), 0, st, b);
         }
         if (update) {
             UpdArgs u;
@@ -1275,8 +1331,8 @@ void launch_blur(tw_engine* e, hipStream_t st, int w, int h, int ld, long long p
 #ifdef TW_VARIANTS
     if (e->win_m == 15 && e->blur_variant == 8) {
         // packed-f32 structure (same speed as v4 at 1080p, lower VALU load); TW_BLUR_VARIANT=8 for A/B
-        if (wide) hipLaunchKernelGGL((tw_blur_solve8<15, 256, 16, 8, true, true>), dim3((w + 223) / 224, gy, npairs), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((tw_blur_solve8<15, 128, 16, 8, true, true>), dim3((w + 95) / 96, gy, npairs), dim3(128), 0, st, a);
+        if (wide) TW_LAUNCH(e, TW_DF_BLUR_SOLVE8, (tw_blur_solve8<15, 256, 16, 8, true, true>), dim3((w + 223) / 224, gy, npairs), dim3(256), 0, st, a);
+        else TW_LAUNCH(e, TW_DF_BLUR_SOLVE8, (tw_blur_solve8<15, 128, 16, 8, true, true>), dim3((w + 95) / 96, gy, npairs), dim3(128), 0, st, a);
         return;
     }
 #endif
@@ -1299,19 +1355,19 @@ void launch_blur(tw_engine* e, hipStream_t st, int w, int h, int ld, long long p
             const dim3 grid((w + a.xsh + tw - 1) / tw, (h + th - 1) / th, npairs);
             if (small == 1) {
                 set_grid_out();
-                hipLaunchKernelGGL((tw_blur_solve4<15, 128, 16, 8, true>), grid, dim3(128), 0, st, a);
+                TW_LAUNCH(e, TW_DF_BLUR_SOLVE4, (tw_blur_solve4<15, 128, 16, 8, true>), grid, dim3(128), 0, st, a);
             }
 #ifdef TW_VARIANTS
-            else if (small == 2) hipLaunchKernelGGL((tw_blur_solve4<15, 128, 16, 4, true>), grid, dim3(128), 0, st, a);
-            else if (small == 3) hipLaunchKernelGGL((tw_blur_solve4<15, 64, 16, 4, true>), grid, dim3(64), 0, st, a);
-            else if (small == 5) hipLaunchKernelGGL((tw_blur_solve_pp<15, 128, 16, 8>), grid, dim3(640), 0, st, a);
+            else if (small == 2) TW_LAUNCH(e, TW_DF_BLUR_SOLVE4, (tw_blur_solve4<15, 128, 16, 4, true>), grid, dim3(128), 0, st, a);
+            else if (small == 3) TW_LAUNCH(e, TW_DF_BLUR_SOLVE4, (tw_blur_solve4<15, 64, 16, 4, true>), grid, dim3(64), 0, st, a);
+            else if (small == 5) TW_LAUNCH(e, TW_DF_BLUR_PP, (tw_blur_solve_pp<15, 128, 16, 8>), grid, dim3(640), 0, st, a);
 #endif
             else if (side && side_used && side->kind == 1) {
                 const TwinGrid t = make_twin(grid, *side);
-                hipLaunchKernelGGL(tw_twin_pp_poly, dim3(t.nA8 + side->n()), dim3(320), 0, st, a, side->pa, t);
+                TW_LAUNCH(e, TW_DF_TWIN, tw_twin_pp_poly, dim3(t.nA8 + side->n()), dim3(320), 0, st, a, side->pa, t);
                 *side_used = true;
             }
-            else hipLaunchKernelGGL((tw_blur_solve_pp<15, 64, 16, 8>), grid, dim3(320), 0, st, a);
+            else TW_LAUNCH(e, TW_DF_BLUR_PP, (tw_blur_solve_pp<15, 64, 16, 8>), grid, dim3(320), 0, st, a);
             return;
         }
 #ifdef TW_VARIANTS
@@ -1320,8 +1376,8 @@ void launch_blur(tw_engine* e, hipStream_t st, int w, int h, int ld, long long p
             a.xsh = ((w + 16 + 223) / 224 == (w + 223) / 224) ? 16 : 0;
             a.rot = a.xsh;
             const dim3 grid((w + a.xsh + 223) / 224, gy, npairs);
-            if (e->blur_variant == 60) hipLaunchKernelGGL((tw_blur_solve6<15, 256, 16, 8, 5>), grid, dim3(256), 0, st, a);
-            else hipLaunchKernelGGL((tw_blur_solve6<15, 256, 16, 8, 4>), grid, dim3(256), 0, st, a);
+            if (e->blur_variant == 60) TW_LAUNCH(e, TW_DF_BLUR_VARIANT, (tw_blur_solve6<15, 256, 16, 8, 5>), grid, dim3(256), 0, st, a);
+            else TW_LAUNCH(e, TW_DF_BLUR_VARIANT, (tw_blur_solve6<15, 256, 16, 8, 4>), grid, dim3(256), 0, st, a);
             return;
         }
         if (wide && e->blur_variant == 5 && w >= 960) {
@@ -1330,7 +1386,7 @@ void launch_blur(tw_engine* e, hipStream_t st, int w, int h, int ld, long long p
             // 3840-pixel rows are covered exactly (nine 224-column tiles cover 2016)
             a.xsh = ((w + 16 + 479) / 480 == (w + 479) / 480) ? 16 : 0;
             a.rot = a.xsh;
-            hipLaunchKernelGGL((tw_blur_solve4<15, 512, 16, 8, true>), dim3((w + a.xsh + 479) / 480, gy, npairs), dim3(512), 0, st, a);
+            TW_LAUNCH(e, TW_DF_BLUR_SOLVE4, (tw_blur_solve4<15, 512, 16, 8, true>), dim3((w + a.xsh + 479) / 480, gy, npairs), dim3(512), 0, st, a);
             return;
         }
 #endif
@@ -1340,13 +1396,13 @@ void launch_blur(tw_engine* e, hipStream_t st, int w, int h, int ld, long long p
         a.rot = a.xsh;
 #ifdef TW_VARIANTS
         if (e->blur_variant == 9) {  // round 4: solve + refresh by the horizontal item's owner, 16-byte R0 / M accesses
-            if (wide) hipLaunchKernelGGL((tw_blur_solve4q<15, 256, 16, 8, true>), dim3((w + a.xsh + 223) / 224, gy, npairs), dim3(256), 0, st, a);
-            else hipLaunchKernelGGL((tw_blur_solve4q<15, 128, 16, 8, true>), dim3((w + a.xsh + 95) / 96, gy, npairs), dim3(128), 0, st, a);
+            if (wide) TW_LAUNCH(e, TW_DF_BLUR_VARIANT, (tw_blur_solve4q<15, 256, 16, 8, true>), dim3((w + a.xsh + 223) / 224, gy, npairs), dim3(256), 0, st, a);
+            else TW_LAUNCH(e, TW_DF_BLUR_VARIANT, (tw_blur_solve4q<15, 128, 16, 8, true>), dim3((w + a.xsh + 95) / 96, gy, npairs), dim3(128), 0, st, a);
             return;
         }
-        if (wide && e->blur_variant == 2) { hipLaunchKernelGGL((tw_blur_solve4y<15, 256, 16, 8, 2>), dim3((w + a.xsh + 223) / 224, (h + 15) / 16, npairs), dim3(256), 0, st, a); return; }
-        if (wide && e->blur_variant == 7) { hipLaunchKernelGGL((tw_blur_solve4<15, 256, 16, 8, true, 2, 2, 2, true, false>), dim3((w + a.xsh + 223) / 224, gy, npairs), dim3(256), 0, st, a); return; }
-        if (wide && e->blur_variant == 6) { hipLaunchKernelGGL((tw_blur_solve4<15, 256, 16, 8, true, 2, 2, 2, false>), dim3((w + a.xsh + 223) / 224, gy, npairs), dim3(256), 0, st, a); return; }
+        if (wide && e->blur_variant == 2) { TW_LAUNCH(e, TW_DF_BLUR_SOLVE4Y, (tw_blur_solve4y<15, 256, 16, 8, 2>), dim3((w + a.xsh + 223) / 224, (h + 15) / 16, npairs), dim3(256), 0, st, a); return; }
+        if (wide && e->blur_variant == 7) { TW_LAUNCH(e, TW_DF_BLUR_SOLVE4, (tw_blur_solve4<15, 256, 16, 8, true, 2, 2, 2, true, false>), dim3((w + a.xsh + 223) / 224, gy, npairs), dim3(256), 0, st, a); return; }
+        if (wide && e->blur_variant == 6) { TW_LAUNCH(e, TW_DF_BLUR_SOLVE4, (tw_blur_solve4<15, 256, 16, 8, true, 2, 2, 2, false>), dim3((w + a.xsh + 223) / 224, gy, npairs), dim3(256), 0, st, a); return; }
 #endif
 #ifdef TW_VARIANTS
         if (wide && update && e->blur_pipe > 0) {
@@ -1354,38 +1410,38 @@ void launch_blur(tw_engine* e, hipStream_t st, int w, int h, int ld, long long p
             const int nt = e->blur_pipe;
             const dim3 grid((w + a.xsh + 223) / 224, (gy + nt - 1) / nt, npairs);
             switch (nt) {
-                case 3: hipLaunchKernelGGL((tw_blur_solve4p<15, 256, 16, 8, 3>), grid, dim3(256), 0, st, a); return;
-                case 5: hipLaunchKernelGGL((tw_blur_solve4p<15, 256, 16, 8, 5>), grid, dim3(256), 0, st, a); return;
-                case 9: hipLaunchKernelGGL((tw_blur_solve4p<15, 256, 16, 8, 9>), grid, dim3(256), 0, st, a); return;
-                case 15: hipLaunchKernelGGL((tw_blur_solve4p<15, 256, 16, 8, 15>), grid, dim3(256), 0, st, a); return;
-                case 109: hipLaunchKernelGGL((tw_blur_solve4p<15, 256, 16, 8, 9, 3>), dim3(grid.x, (gy + 8) / 9, npairs), dim3(256), 0, st, a); return;
+                case 3: TW_LAUNCH(e, TW_DF_BLUR_VARIANT, (tw_blur_solve4p<15, 256, 16, 8, 3>), grid, dim3(256), 0, st, a); return;
+                case 5: TW_LAUNCH(e, TW_DF_BLUR_VARIANT, (tw_blur_solve4p<15, 256, 16, 8, 5>), grid, dim3(256), 0, st, a); return;
+                case 9: TW_LAUNCH(e, TW_DF_BLUR_VARIANT, (tw_blur_solve4p<15, 256, 16, 8, 9>), grid, dim3(256), 0, st, a); return;
+                case 15: TW_LAUNCH(e, TW_DF_BLUR_VARIANT, (tw_blur_solve4p<15, 256, 16, 8, 15>), grid, dim3(256), 0, st, a); return;
+                case 109: TW_LAUNCH(e, TW_DF_BLUR_VARIANT, (tw_blur_solve4p<15, 256, 16, 8, 9, 3>), dim3(grid.x, (gy + 8) / 9, npairs), dim3(256), 0, st, a); return;
                 default: break;
             }
         }
 #endif
         set_grid_out();
-        if (wide) hipLaunchKernelGGL((tw_blur_solve4<15, 256, 16, 8, true>), dim3((w + a.xsh + 223) / 224, gy, npairs), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((tw_blur_solve4<15, 128, 16, 8, true>), dim3((w + a.xsh + 95) / 96, gy, npairs), dim3(128), 0, st, a);
+        if (wide) TW_LAUNCH(e, TW_DF_BLUR_SOLVE4, (tw_blur_solve4<15, 256, 16, 8, true>), dim3((w + a.xsh + 223) / 224, gy, npairs), dim3(256), 0, st, a);
+        else TW_LAUNCH(e, TW_DF_BLUR_SOLVE4, (tw_blur_solve4<15, 128, 16, 8, true>), dim3((w + a.xsh + 95) / 96, gy, npairs), dim3(128), 0, st, a);
     } else if (e->win_m == 25) {
         // winSize 50/51 (BASELINE config 5): packed-f32 structure, single 58-row register window
 #ifdef TW_VARIANTS
-        if (wide && e->blur_variant == 8) { hipLaunchKernelGGL((tw_blur_solve8<25, 256, 32, 8, true, false>), dim3((w + 191) / 192, gy, npairs), dim3(256), 0, st, a); return; }
+        if (wide && e->blur_variant == 8) { TW_LAUNCH(e, TW_DF_BLUR_SOLVE8, (tw_blur_solve8<25, 256, 32, 8, true, false>), dim3((w + 191) / 192, gy, npairs), dim3(256), 0, st, a); return; }
         // round 3 trials for config 5: shorter tiles make room for the R0 prefetch (QPRE)
-        if (wide && e->blur_variant == 256) { hipLaunchKernelGGL((tw_blur_solve4<25, 256, 32, 6, true, 2, 2, 2, true, false>), dim3((w + 191) / 192, (h + 5) / 6, npairs), dim3(256), 0, st, a); return; }
-        if (wide && e->blur_variant == 255) { hipLaunchKernelGGL((tw_blur_solve4<25, 256, 32, 5, true, 2, 2, 2, true, false>), dim3((w + 191) / 192, (h + 4) / 5, npairs), dim3(256), 0, st, a); return; }
-        if (wide && e->blur_variant == 254) { hipLaunchKernelGGL((tw_blur_solve4<25, 256, 32, 4, true, 2, 2, 2, true, false>), dim3((w + 191) / 192, (h + 3) / 4, npairs), dim3(256), 0, st, a); return; }
-        if (wide && e->blur_variant == 258) { hipLaunchKernelGGL((tw_blur_solve4<25, 256, 32, 8, true, 2, 2, 2, true, false>), dim3((w + 191) / 192, gy, npairs), dim3(256), 0, st, a); return; }
-        if (wide && e->blur_variant == 41) { hipLaunchKernelGGL((tw_blur_solve4<25, 256, 32, 8, true, 2, 2, 2, false, false>), dim3((w + 191) / 192, gy, npairs), dim3(256), 0, st, a); return; }
-        if (wide && e->blur_variant == 259) { hipLaunchKernelGGL((tw_blur_solve4<25, 256, 32, 5, true, 2, 2, 2, false, false>), dim3((w + 191) / 192, (h + 4) / 5, npairs), dim3(256), 0, st, a); return; }
+        if (wide && e->blur_variant == 256) { TW_LAUNCH(e, TW_DF_BLUR_SOLVE4, (tw_blur_solve4<25, 256, 32, 6, true, 2, 2, 2, true, false>), dim3((w + 191) / 192, (h + 5) / 6, npairs), dim3(256), 0, st, a); return; }
+        if (wide && e->blur_variant == 255) { TW_LAUNCH(e, TW_DF_BLUR_SOLVE4, (tw_blur_solve4<25, 256, 32, 5, true, 2, 2, 2, true, false>), dim3((w + 191) / 192, (h + 4) / 5, npairs), dim3(256), 0, st, a); return; }
+        if (wide && e->blur_variant == 254) { TW_LAUNCH(e, TW_DF_BLUR_SOLVE4, (tw_blur_solve4<25, 256, 32, 4, true, 2, 2, 2, true, false>), dim3((w + 191) / 192, (h + 3) / 4, npairs), dim3(256), 0, st, a); return; }
+        if (wide && e->blur_variant == 258) { TW_LAUNCH(e, TW_DF_BLUR_SOLVE4, (tw_blur_solve4<25, 256, 32, 8, true, 2, 2, 2, true, false>), dim3((w + 191) / 192, gy, npairs), dim3(256), 0, st, a); return; }
+        if (wide && e->blur_variant == 41) { TW_LAUNCH(e, TW_DF_BLUR_SOLVE4, (tw_blur_solve4<25, 256, 32, 8, true, 2, 2, 2, false, false>), dim3((w + 191) / 192, gy, npairs), dim3(256), 0, st, a); return; }
+        if (wide && e->blur_variant == 259) { TW_LAUNCH(e, TW_DF_BLUR_SOLVE4, (tw_blur_solve4<25, 256, 32, 5, true, 2, 2, 2, false, false>), dim3((w + 191) / 192, (h + 4) / 5, npairs), dim3(256), 0, st, a); return; }
 #endif
         // wide levels: two vertically adjacent 8-row sub-tiles share one 66-row register window (round 3: -7 % against the
         // one-sub-tile kernel with its 58-row window per 8 rows, which TW_BLUR_VARIANT=41 of the variants library selects)
-        if (wide) hipLaunchKernelGGL((tw_blur_solve4y<25, 256, 32, 8, 2>), dim3((w + 191) / 192, (h + 15) / 16, npairs), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((tw_blur_solve8<25, 128, 32, 8, true, false>), dim3((w + 63) / 64, gy, npairs), dim3(128), 0, st, a);
+        if (wide) TW_LAUNCH(e, TW_DF_BLUR_SOLVE4Y, (tw_blur_solve4y<25, 256, 32, 8, 2>), dim3((w + 191) / 192, (h + 15) / 16, npairs), dim3(256), 0, st, a);
+        else TW_LAUNCH(e, TW_DF_BLUR_SOLVE8, (tw_blur_solve8<25, 128, 32, 8, true, false>), dim3((w + 63) / 64, gy, npairs), dim3(128), 0, st, a);
     } else {
         // any other window size: generic kernel (same arithmetic, runtime loops)
         const size_t lds = (size_t)5 * BS_TH * (64 + 2 * e->win_m) * 4;
-        hipLaunchKernelGGL(tw_blur_solve_generic, dim3((w + 63) / 64, gy, npairs), dim3(256), lds, st, a);
+        TW_LAUNCH(e, TW_DF_BLUR_GENERIC, tw_blur_solve_generic, dim3((w + 63) / 64, gy, npairs), dim3(256), lds, st, a);
     }
 }
 
@@ -1467,9 +1523,9 @@ tw_status flush_ctx(tw_engine* e, Ctx& c)
         pa.w = c.w;
         pa.h = c.h;
         // waves per image: as many as the 128 KB of LDS row buffers allow for this width
-        if (c.w <= PNG_LDS_PIXELS / 16) hipLaunchKernelGGL(tw_png_unfilter<16>, dim3(2 * n), dim3(1024), 0, e->copy_stream, pa);
-        else if (c.w <= PNG_LDS_PIXELS / 4) hipLaunchKernelGGL(tw_png_unfilter<4>, dim3(2 * n), dim3(256), 0, e->copy_stream, pa);
-        else hipLaunchKernelGGL(tw_png_unfilter<1>, dim3(2 * n), dim3(64), 0, e->copy_stream, pa);
+        if (c.w <= PNG_LDS_PIXELS / 16) TW_LAUNCH(e, TW_DF_PNG_UNFILTER, tw_png_unfilter<16>, dim3(2 * n), dim3(1024), 0, e->copy_stream, pa);
+        else if (c.w <= PNG_LDS_PIXELS / 4) TW_LAUNCH(e, TW_DF_PNG_UNFILTER, tw_png_unfilter<4>, dim3(2 * n), dim3(256), 0, e->copy_stream, pa);
+        else TW_LAUNCH(e, TW_DF_PNG_UNFILTER, tw_png_unfilter<1>, dim3(2 * n), dim3(64), 0, e->copy_stream, pa);
     }
     c.copy_ops_at_flush = e->copy_ops;
     if (c.any_host) {
@@ -1503,8 +1559,7 @@ tw_status flush_ctx(tw_engine* e, Ctx& c)
     for (const LevelPlan& L : pl->lv) ws_lane = std::max(ws_lane, (size_t)L.ps * 2 * L.chunk);
     // one pair: image-only work (pyramid, polynomial expansion) of all levels on the second stream
     // (only worth its cross-stream hand-offs when the image-only work is tens of microseconds: >= 0.1 Mpixel)
-    const bool lat = n == 1 && nlanes == 1 && e->lat_streams && e->lat_I && pl->levels >= 1 &&
-                     (long long)c.w * c.h >= e->lat_min_px;
+    const bool lat = nlanes == 1 && e->lat_I && single_pair_schedule(e, n, c.w, c.h, pl->levels);
     bool prof_on = false;
     for (int i = 0; i < TW_K_COUNT; i++) prof_on = prof_on || e->prof_level[i] != -2;
     // ... or, for the default parameters at sizes whose pyramid halves exactly (1080p: BASELINE config 2), ONE stream of twin
@@ -1525,16 +1580,10 @@ tw_status flush_ctx(tw_engine* e, Ctx& c)
     }
     // Everything between the batch's start event and the ordered scan, as one function: the single-pair schedule
     // replays it from a captured hipGraph (below), every other batch enqueues it directly.
-    // does level k of a launch of nc pairs run tw_flow_iter?  (a launch of fewer workgroups than ~3/4 of the CUs — one or two
-    // 1080p pairs — leaves the chip to the 224 x 8 tiles of tw_blur_solve4, of which a single pair already makes 1 215)
+    // does level k of a launch of nc pairs run tw_flow_iter?  (level_runs_flow_iter: the predicate the byte model shares)
     auto level_mfree = [&](int k, int nc) -> bool {
         const LevelPlan& L = pl->lv[k];
-        const bool grid_only = k == 0 && it > 0 && e->scan_fused && c.span == 10 && e->win_m == 15 && !e->box;
-        const int fi_out = (e->fi_nt == 512 ? FI_SC_512 : FI_SC) - 30;
-        const long long fi_wgs = (long long)((L.w + fi_out - 1) / fi_out) * std::min(4, std::max(1, L.h / (16 * FI_TH))) * nc;
-        return e->mfree && !lat && it > (grid_only ? 1 : 0) && flow_iter_eligible(e, L.w, L.h) &&
-               (fi_wgs * 4 >= (long long)e->cu_count * 3 || e->mfree == 2) &&
-               (e->mfree_min_px <= 0 || (long long)L.w * L.h >= e->mfree_min_px);
+        return level_runs_flow_iter(e, L.w, L.h, nc, lat, k == 0 && scan_fused_level0(e, c.span));
     };
     auto enqueue_levels = [&]() -> tw_status {
     if (lat && !lat2) {
@@ -1654,8 +1703,7 @@ tw_status flush_ctx(tw_engine* e, Ctx& c)
             const LevelPlan& L = pl->lv[k];
             RoctxRange level_range("tw_level %d (%dx%d)", k, L.w, L.h);
             // balanced launches: 64 pairs with a 63-pair chunk are 32 + 32, not 63 + 1
-            const int nlaunch = (hi - lo + L.chunk - 1) / L.chunk;
-            const int per = nlaunch > 0 ? (hi - lo + nlaunch - 1) / nlaunch : 1;
+            const int per = balanced_launch_pairs(hi - lo, L.chunk);
             for (int j0 = lo; j0 < hi; j0 += per) {
                 const int nc = std::min(per, hi - j0);
                 // flow buffers: levels >= 1 keep every pair of the batch, level 0 only the lane's current chunk
@@ -1677,7 +1725,7 @@ tw_status flush_ctx(tw_engine* e, Ctx& c)
                     // overwrite the first chunk's level-2 images before level 2 reads them)
                     const bool f23 = pl->fused23 && e->pyr_fused && pl->lv[3].chunk >= hi - lo && pl->lv[2].chunk >= hi - lo &&
                                      (size_t)(pl->lv[3].ps + pl->lv[2].ps) * 2 * nc <= ws_lane;
-                    float* I2side = I + (size_t)pl->lv[3].ps * 2 * nc;
+                    float* I2side = f23 ? I + (size_t)pl->lv[3].ps * 2 * nc : nullptr;  // (a plan may have fewer than 4 levels: ADVICE r5)
                     // levels 1 and 0 likewise (tw_pyr_k3f): level 0's images wait in the M1 region, which nothing else
                     // touches while levels 1 and 0 both run tw_flow_iter (their iterations ping-pong through M0 only) and
                     // which is large enough (5 planes per pair against 2 images of one)
@@ -1695,7 +1743,7 @@ tw_status flush_ctx(tw_engine* e, Ctx& c)
                 // flow buffer and the (now unused) M0 workspace so that the last iteration lands in the flow buffer.
                 // scan-fused final iteration (option TW_OPT_SCAN_FUSED_FINAL): nothing but the span grid of the last
                 // level-0 flow is read afterwards, so the last window average + solve runs at the grid points only
-                const bool grid_only = k == 0 && it > 0 && e->scan_fused && c.span == 10 && e->win_m == 15 && !e->box;
+                const bool grid_only = k == 0 && scan_fused_level0(e, c.span);
                 bool iterated = false;
                 bool grid_stored = false;  // the last window launch wrote the span-grid samples itself (single pair)
                 // (with the scan-fused last iteration: it - 1 iterations here, then the M of the last flow from
@@ -1743,7 +1791,7 @@ tw_status flush_ctx(tw_engine* e, Ctx& c)
                         g.g = e->d_grid + (size_t)j0 * g.gw * g.gh;
                         g.c = e->wc;
                         ProfScope pscope(e, ls, TW_K_BLUR_SOLVE, 0);
-                        hipLaunchKernelGGL((tw_blur_grid<15, 10, 2>), dim3((g.gw + 21) / 22, (g.gh + 1) / 2, nc), dim3(256), 0, ls, g);
+                        TW_LAUNCH(e, TW_DF_BLUR_GRID, (tw_blur_grid<15, 10, 2>), dim3((g.gw + 21) / 22, (g.gh + 1) / 2, nc), dim3(256), 0, ls, g);
                     }
                     iterated = true;
                 }
@@ -1770,7 +1818,7 @@ tw_status flush_ctx(tw_engine* e, Ctx& c)
                         g.g = e->d_grid + (size_t)j0 * g.gw * g.gh;
                         g.c = e->wc;
                         ProfScope pscope(e, ls, TW_K_BLUR_SOLVE, 0);
-                        hipLaunchKernelGGL((tw_blur_grid<15, 10, 2>), dim3((g.gw + 21) / 22, (g.gh + 1) / 2, nc), dim3(256), 0, ls, g);
+                        TW_LAUNCH(e, TW_DF_BLUR_GRID, (tw_blur_grid<15, 10, 2>), dim3((g.gw + 21) / 22, (g.gh + 1) / 2, nc), dim3(256), 0, ls, g);
                         break;
                     }
                     if (lat2 && k >= 2) {
@@ -1806,7 +1854,7 @@ tw_status flush_ctx(tw_engine* e, Ctx& c)
                     g.gh = (L.h + c.span - 1) / c.span;
                     g.g = e->d_grid + (size_t)j0 * g.gw * g.gh;
                     ProfScope pscope(e, ls, TW_K_SCAN, 0);
-                    hipLaunchKernelGGL(tw_span_gather, dim3((g.gw + 63) / 64, (g.gh + 3) / 4, nc), dim3(256), 0, ls, g);
+                    TW_LAUNCH(e, TW_DF_SPAN_GATHER, tw_span_gather, dim3((g.gw + 63) / 64, (g.gh + 3) / 4, nc), dim3(256), 0, ls, g);
                 }
                 // the image-only work two levels below goes out once this level's chain is enqueued
                 if (lat && !lat2 && k >= 2 && (r = lat_images(k - 2))) return r;
@@ -1887,10 +1935,10 @@ tw_status flush_ctx(tw_engine* e, Ctx& c)
 #ifdef TW_VARIANTS
         static const bool scan_direct = getenv("TW_SCAN_DIRECT") != nullptr;
         if (lat && !grid_only && scan_direct) {
-            hipLaunchKernelGGL(tw_span_scan<true>, dim3(n), dim3(1024), 0, st, a);
+            TW_LAUNCH(e, TW_DF_SPAN_SCAN, tw_span_scan<true>, dim3(n), dim3(1024), 0, st, a);
         } else
 #endif
-        hipLaunchKernelGGL(tw_span_scan<false>, dim3(n), dim3(1024), 0, st, a);
+        TW_LAUNCH(e, TW_DF_SPAN_SCAN, tw_span_scan<false>, dim3(n), dim3(1024), 0, st, a);
     }
     TW_HIP(e, hipEventRecord(c.ev_stop, st));
     if (c.span > 0) {
@@ -2198,6 +2246,8 @@ void tw_default_params(tw_params* p)
     p->flags = 256;
 }
 
+int tw_abi_version(void) { return TWFLOW_ABI_VERSION; }
+
 int tw_has_variants(void)
 {
 #ifdef TW_VARIANTS
@@ -2331,6 +2381,7 @@ tw_status tw_engine_create(int device, const tw_params* params, int slots, tw_en
     if (const char* ev = getenv("TW_LAT_FUSED")) e->lat_fused = atoi(ev) ? 1 : 0;
 #ifdef TW_VARIANTS
     if (const char* ev = getenv("TW_FI_NT")) e->fi_nt = atoi(ev) == 512 ? 512 : 1024;
+    if (const char* ev = getenv("TW_FI_SKIP")) e->fi_skip = atoi(ev);
 #endif
     if (const char* ev = getenv("TW_LAT_S2_LEVELS")) e->lat_s2_max = atoi(ev);
     // the main stream carries the dependent flow chain: highest priority, so that its small launches are not queued
@@ -2712,9 +2763,27 @@ int tw_level_chunk(tw_engine* e, int width, int height, int level)
     return pl->lv[level].chunk;
 }
 
+int tw_level_runs_flow_iter(const tw_engine* e, int width, int height, int level, int npairs)
+{
+    if (!e || npairs < 1) return -1;
+    const int L = tw_num_levels(e, width, height);
+    if (level < 0 || level > L) return -1;
+    int w, h, ks;
+    double sg, sc;
+    level_geometry(width, height, e->p.pyrScale, level, &w, &h, &sg, &ks, &sc);
+    const int nc = balanced_launch_pairs(npairs, pairs_per_launch(e, w, h, level));
+    return level_runs_flow_iter(e, w, h, nc, single_pair_schedule(e, npairs, width, height, L),
+                                level == 0 && scan_fused_level0(e, 10)) ? 1 : 0;
+}
+
 double tw_algorithmic_bytes(const tw_engine* e, int kclass, int level, int width, int height)
 {
-    if (!e) return 0;
+    return e ? tw_algorithmic_bytes_launch(e, kclass, level, width, height, e->cap) : 0;
+}
+
+double tw_algorithmic_bytes_launch(const tw_engine* e, int kclass, int level, int width, int height, int npairs)
+{
+    if (!e || npairs < 1) return 0;
     const int L = tw_num_levels(e, width, height);
     if (level < 0 || level > L) return 0;
     int w, h, ks;
@@ -2722,21 +2791,31 @@ double tw_algorithmic_bytes(const tw_engine* e, int kclass, int level, int width
     level_geometry(width, height, e->p.pyrScale, level, &w, &h, &sg, &ks, &sc);
     const double N = (double)w * h, N0 = (double)width * height;
     const int it = e->p.pyrIterations;
-    // round 5, as built in the batch path: levels that run tw_flow_iter have no FarnebackUpdateMatrices launch and no M
-    // planes (flow 8N + R0 20N + R1 20N in, flow 8N out = 56N per iteration; the first one reads the coarser level's flow,
-    // 8 N_{k+1}, instead of this level's); levels 3 and 2 of an exact-halving pyramid come from one read of the images
-    const bool mfree = e->mfree && it > 0 && flow_iter_eligible(e, w, h) &&
-                       (e->mfree_min_px <= 0 || (long long)w * h >= e->mfree_min_px);
+    // as built (round 5), with the SAME predicates as the schedule (flush_ctx): levels that run tw_flow_iter have no
+    // FarnebackUpdateMatrices launch and no M planes (flow 8N + R0 20N + R1 20N in, flow 8N out = 56N per iteration; the first
+    // one reads the coarser level's flow, 8 N_{k+1}, instead of this level's); levels 3 and 2 of an exact-halving pyramid come
+    // from one read of the images.  A single pair, a small batch or a narrow level keeps tw_update_matrices + tw_blur_solve*.
+    const bool mfree = tw_level_runs_flow_iter(e, width, height, level, npairs) == 1;
+    const bool lat = single_pair_schedule(e, npairs, width, height, L);
+    auto whole_batch = [&](int k) {  // one launch covers the batch at level k
+        int wk, hk;
+        level_geometry(width, height, e->p.pyrScale, k, &wk, &hk, &sg, &ks, &sc);
+        return pairs_per_launch(e, wk, hk, k) >= npairs;
+    };
     const bool fused23 = e->pyr_fused && L >= 3 && e->p.pyrScale == 0.5 && width % 8 == 0 && height % 8 == 0 && width >= 64 &&
-                         height >= 64;
+                         height >= 64 && (lat || (whole_batch(3) && whole_batch(2)));
     switch (kclass) {
         case TW_K_PYR: {
             if (fused23 && level == 2) return 2 * (4 * N);  // written by level 3's launch
-            // levels 1 and 0 from one read (tw_pyr_k3f) when both run tw_flow_iter and level 1 is an exact halving
+            // levels 1 and 0 from one read (tw_pyr_k3f) when both run tw_flow_iter, level 1 is an exact halving and a launch
+            // covers the batch at both levels (the single-pair schedule's twin launches carry tw_pyr_k3f as well)
             int w1 = 0, h1 = 0;
             if (L >= 1) level_geometry(width, height, e->p.pyrScale, 1, &w1, &h1, &sg, &ks, &sc);
-            const bool fused01 = e->pyr_fused && !e->pyr_generic && L >= 1 && width == 2 * w1 && height == 2 * h1 && width >= 16 &&
-                                 e->mfree && it > 0 && flow_iter_eligible(e, width, height) && flow_iter_eligible(e, w1, h1);
+            const bool exact01 = e->pyr_fused && !e->pyr_generic && L >= 1 && width == 2 * w1 && height == 2 * h1 && width >= 16;
+            const bool fused01 = exact01 && (lat ? (e->lat_fused && L == 3 && fused23)
+                                                 : (whole_batch(0) && whole_batch(1) &&
+                                                    tw_level_runs_flow_iter(e, width, height, 0, npairs) == 1 &&
+                                                    tw_level_runs_flow_iter(e, width, height, 1, npairs) == 1));
             if (fused01 && level == 0) return 2 * (4 * N);  // written by level 1's launch
             return 2 * (N0 + 4 * N);
         }
@@ -2867,6 +2946,75 @@ extern "C" int tw_debug_stamps_ex(tw_engine* e, unsigned long long* out, int n)
 
 // number of captured single-pair schedules this engine holds (tests: the graph path is really the one that ran)
 extern "C" int tw_debug_graphs(tw_engine* e) { return e ? (int)e->lat_graphs.size() : -1; }
+
+extern "C" int tw_debug_launch_counts(tw_engine* e, unsigned long long* counts, unsigned long long* last_z, int n, int reset)
+{
+    if (!e) return -1;
+    for (int i = 0; i < n && i < TW_DF_COUNT; i++) {
+        if (counts) counts[i] = e->launches[i];
+        if (last_z) last_z[i] = e->last_grid_z[i];
+    }
+    if (reset) {
+        memset(e->launches, 0, sizeof(e->launches));
+        memset(e->last_grid_z, 0, sizeof(e->last_grid_z));
+    }
+    return TW_DF_COUNT;
+}
+
+extern "C" const char* tw_debug_family_name(int family)
+{
+    static const char* const names[TW_DF_COUNT] = {
+        "tw_pyr_k3", "tw_pyr_k3f", "tw_pyr_23", "tw_pyr_taps", "tw_pyr_level", "tw_polyexp", "tw_update_matrices",
+        "tw_flow_iter", "tw_flow_iter_ups", "tw_flow_iter_zero", "tw_blur_solve4", "tw_blur_solve4y", "tw_blur_solve8",
+        "tw_blur_solve_pp", "tw_blur_solve_generic", "tw_blur_variant", "tw_blur_grid", "tw_box", "tw_twin",
+        "tw_span_gather", "tw_span_scan", "tw_png_unfilter"};
+    return (family >= 0 && family < TW_DF_COUNT) ? names[family] : nullptr;
+}
+
+extern "C" int tw_debug_memory(tw_engine* e, unsigned long long* out, int n)
+{
+    if (!e || !out) return -1;
+    unsigned long long v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // device: the level workspace (I + 5 I for R + 2 x 2.5 I for M), the single-pair schedule's I / R, the box window's column
+    // sums, flow planes, the dense grid, pointer / count tables, debug stamps, every context's images, filtered rows, PNG job
+    // table and records, and the plans' tables (each allocation with the slack it was made with)
+    if (e->I) v[0] += (e->ws_elems * 4 + 256) + (e->ws_elems * 5 * 4 + 256) + 2 * (e->ws_elems / 2 * 5 * 4 + 256);
+    if (e->lat_I) v[0] += (e->lat_cap * 4 + 256) + (e->lat_cap * 5 * 4 + 256);
+    if (e->Vd) v[0] += e->Vd_cap * sizeof(double) + 256;
+    for (size_t k = 0; k < e->flow.size(); k++)
+        if (e->flow[k]) v[0] += e->flow_cap[k] * 4 + 256;
+    if (e->d_grid) v[0] += e->d_grid_cap * sizeof(float2) + 256;
+    if (e->d_ptrs) v[0] += sizeof(void*) * 2 * (size_t)e->cap + 256;
+    if (e->d_count) v[0] += sizeof(int) * (size_t)e->cap + 256;
+    if (e->dbg_stamps) v[0] += 4096 * sizeof(unsigned long long);
+    for (const Ctx& c : e->ctx) {
+        if (c.d_img) v[0] += c.d_img_cap + 256;
+        if (c.d_filt_raw) v[0] += c.d_filt_cap + 512;
+        if (c.d_png) v[0] += sizeof(PngJob) * 2 * (size_t)e->cap + 256;
+        if (c.d_rec) v[0] += c.d_rec_cap * sizeof(ScanRec) + 256;
+        if (c.h_img) v[1] += c.h_img_cap;
+        if (c.h_ptrs) v[1] += sizeof(void*) * 2 * (size_t)e->cap;
+        if (c.h_count) v[1] += sizeof(int) * (size_t)e->cap;
+        if (c.h_png) v[1] += sizeof(PngJob) * 2 * (size_t)e->cap;
+        if (c.h_rec) v[1] += sizeof(ScanRec) * HOST_RECS * (size_t)e->cap;
+    }
+    for (const auto& kv : e->plans) v[0] += kv.second->owned_bytes;
+    v[1] += e->h_bounce_cap;
+    v[2] = e->plans.size();
+    v[3] = e->h_bounce_cap;
+    {
+        PinRegistry& r = pin_registry();
+        std::lock_guard<std::mutex> lk(r.m);
+        v[4] = r.ranges.size();
+        for (const auto& kv : r.ranges) v[5] += kv.second.bytes;
+    }
+    v[6] = e->prof_free.size();
+    for (int i = 0; i < TW_K_COUNT; i++) v[6] += 2 * e->prof_pending[i].size();
+    v[7] = e->lat_graphs.size();
+    int i = 0;
+    for (; i < n && i < 8; i++) out[i] = v[i];
+    return i;
+}
 
 // occupancy report of the main kernels (workgroups per CU the runtime admits) — tools/kbench.py
 extern "C" int tw_debug_occupancy(char* buf, int cap)
@@ -3034,12 +3182,12 @@ extern "C" tw_status tw_bench_stage(tw_engine* e, int kclass, int width, int hei
                 GatherArgs g;
                 g.flow = fl; g.fzs = 2 * L.ps; g.fps = L.ps; g.ld = L.ld; g.span = span;
                 g.gw = (L.w + span - 1) / span; g.gh = (L.h + span - 1) / span; g.g = grid;
-                hipLaunchKernelGGL(tw_span_gather, dim3((g.gw + 63) / 64, (g.gh + 3) / 4, npairs), dim3(256), 0, st, g);
+                TW_LAUNCH(e, TW_DF_SPAN_GATHER, tw_span_gather, dim3((g.gw + 63) / 64, (g.gh + 3) / 4, npairs), dim3(256), 0, st, g);
                 ScanArgs a;
                 a.g = grid; a.span = span; a.gw = g.gw; a.gh = g.gh; a.thr2 = 4.0; a.count = cnt;
                 a.rec = rec; a.rec_zs = (long long)a.gw * a.gh;
                 a.flow = nullptr; a.fps = 0; a.ld = 0;
-                hipLaunchKernelGGL(tw_span_scan<false>, dim3(npairs), dim3(1024), 0, st, a);
+                TW_LAUNCH(e, TW_DF_SPAN_SCAN, tw_span_scan<false>, dim3(npairs), dim3(1024), 0, st, a);
             } break;
         }
         return TW_OK;
@@ -3185,9 +3333,9 @@ tw_status tw_stage_png_unfilter(tw_engine* e, const uint8_t* rows, int channels,
     pa.w = w;
     pa.h = h;
     hipStream_t st = e->stream;
-    if (waves == 16) hipLaunchKernelGGL(tw_png_unfilter<16>, dim3(1), dim3(1024), 0, st, pa);
-    else if (waves == 4) hipLaunchKernelGGL(tw_png_unfilter<4>, dim3(1), dim3(256), 0, st, pa);
-    else hipLaunchKernelGGL(tw_png_unfilter<1>, dim3(1), dim3(64), 0, st, pa);
+    if (waves == 16) TW_LAUNCH(e, TW_DF_PNG_UNFILTER, tw_png_unfilter<16>, dim3(1), dim3(1024), 0, st, pa);
+    else if (waves == 4) TW_LAUNCH(e, TW_DF_PNG_UNFILTER, tw_png_unfilter<4>, dim3(1), dim3(256), 0, st, pa);
+    else TW_LAUNCH(e, TW_DF_PNG_UNFILTER, tw_png_unfilter<1>, dim3(1), dim3(64), 0, st, pa);
     TW_HIP(e, hipGetLastError());
     TW_HIP(e, hipStreamSynchronize(st));
     TW_TRY(d2h_sync(e, gray, d_gray, (size_t)w * h));

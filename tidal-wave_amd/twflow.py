@@ -48,13 +48,14 @@ OPT_SCAN_FUSED_FINAL = 1
 OPT_POLYEXP_F32 = 2
 
 SYMBOLS = [
-    "tw_default_params", "tw_has_variants", "tw_device_count", "tw_device_pci_bus_id", "tw_engine_create", "tw_engine_destroy", "tw_strerror",
+    "tw_default_params", "tw_abi_version", "tw_has_variants", "tw_device_count", "tw_device_pci_bus_id", "tw_engine_create", "tw_engine_destroy", "tw_strerror",
     "tw_last_error", "tw_flow_u8", "tw_diff_u8", "tw_submit_u8", "tw_submit_png8", "tw_submit_dev", "tw_flush", "tw_wait",
     "tw_grid_capacity", "tw_dev_alloc", "tw_dev_free", "tw_dev_upload", "tw_host_alloc", "tw_host_free", "tw_host_register", "tw_host_unregister", "tw_set_option",
     "tw_prof_select", "tw_prof_read",
-    "tw_algorithmic_bytes", "tw_algorithmic_bytes_pair", "tw_min_traffic_bytes_pair", "tw_num_levels", "tw_level_chunk", "tw_bench_stage", "tw_stage_pyr_level", "tw_stage_pyr_fused23", "tw_stage_pyr_fused01",
+    "tw_algorithmic_bytes", "tw_algorithmic_bytes_launch", "tw_level_runs_flow_iter", "tw_algorithmic_bytes_pair", "tw_min_traffic_bytes_pair", "tw_num_levels", "tw_level_chunk", "tw_bench_stage", "tw_stage_pyr_level", "tw_stage_pyr_fused23", "tw_stage_pyr_fused01",
     "tw_stage_png_unfilter", "tw_stage_polyexp", "tw_stage_update_matrices", "tw_stage_flow_upsample_update", "tw_stage_blur_solve", "tw_stage_flow_iter",
     "tw_debug_graphs", "tw_debug_occupancy", "tw_debug_stamps", "tw_debug_stamps_ex", "tw_debug_copy_rate",
+    "tw_debug_launch_counts", "tw_debug_family_name", "tw_debug_memory",
 ]
 
 
@@ -155,7 +156,30 @@ def _bind(path):
     L.tw_debug_copy_rate.argtypes = [vp, C.c_size_t, C.c_int, C.POINTER(C.c_double)]
     L.tw_debug_graphs.argtypes = [vp]
     L.tw_debug_graphs.restype = C.c_int
+    L.tw_abi_version.restype = C.c_int
+    L.tw_algorithmic_bytes_launch.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.tw_algorithmic_bytes_launch.restype = C.c_double
+    L.tw_level_runs_flow_iter.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.tw_level_runs_flow_iter.restype = C.c_int
+    u64p = C.POINTER(C.c_uint64)
+    L.tw_debug_launch_counts.argtypes = [vp, u64p, u64p, C.c_int, C.c_int]
+    L.tw_debug_launch_counts.restype = C.c_int
+    L.tw_debug_family_name.argtypes = [C.c_int]
+    L.tw_debug_family_name.restype = C.c_char_p
+    L.tw_debug_memory.argtypes = [vp, u64p, C.c_int]
+    L.tw_debug_memory.restype = C.c_int
     return L
+
+
+class LaunchCounts(dict):
+    """Engine.launch_counts(): family -> launches; .last_z: family -> grid z (pairs / images) of its latest launch."""
+
+    def flow_iter(self):
+        return self["tw_flow_iter"] + self["tw_flow_iter_ups"] + self["tw_flow_iter_zero"]
+
+
+def abi_version():
+    return lib().tw_abi_version()
 
 
 def default_params(**kw):
@@ -371,8 +395,33 @@ class Engine:
         self._check(self._L.tw_prof_read(self._h, kclass, C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
-    def algorithmic_bytes(self, kclass, level, w, h):
-        return self._L.tw_algorithmic_bytes(self._h, kclass, level, w, h)
+    def algorithmic_bytes(self, kclass, level, w, h, npairs=None):
+        """Bytes one launch of `kclass` at `level` must move per pair; npairs: the batch (default: the engine's slots)."""
+        if npairs is None:
+            return self._L.tw_algorithmic_bytes(self._h, kclass, level, w, h)
+        return self._L.tw_algorithmic_bytes_launch(self._h, kclass, level, w, h, npairs)
+
+    def level_runs_flow_iter(self, w, h, level, npairs):
+        """Does `level` of a batch of npairs pairs run tw_flow_iter (the schedule's own predicate)?"""
+        return self._L.tw_level_runs_flow_iter(self._h, w, h, level, npairs) == 1
+
+    def launch_counts(self, reset=False):
+        """{family name: launches} since creation / the last reset, every family (twflow_debug.h)."""
+        n = self._L.tw_debug_launch_counts(self._h, None, None, 0, 0)
+        cnt = (C.c_uint64 * n)()
+        z = (C.c_uint64 * n)()
+        self._L.tw_debug_launch_counts(self._h, cnt, z, n, 1 if reset else 0)
+        out = LaunchCounts((self._L.tw_debug_family_name(i).decode(), int(cnt[i])) for i in range(n))
+        out.last_z = {self._L.tw_debug_family_name(i).decode(): int(z[i]) for i in range(n)}
+        return out
+
+    def memory(self):
+        """The library's own byte accounting of this engine (twflow_debug.h: tw_debug_memory)."""
+        v = (C.c_uint64 * 8)()
+        n = self._L.tw_debug_memory(self._h, v, 8)
+        keys = ("device_bytes", "pinned_host_bytes", "plans", "bounce_bytes", "pagelock_entries", "pagelock_bytes",
+                "prof_events", "graphs")
+        return {k: int(v[i]) for i, k in enumerate(keys[:n])}
 
     def algorithmic_bytes_pair(self, w, h, span):
         return self._L.tw_algorithmic_bytes_pair(self._h, w, h, span)

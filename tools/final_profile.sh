@@ -54,6 +54,20 @@ for c in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$out/pmc5_$c" -o run -- python3 tools/bench_config5.py 16 2 > "$out/pmc5_$c.log" 2>&1
 done
 python3 tools/pmc_kernel_traffic.py "$out/pmc5_FETCH_SIZE" "$out/pmc5_WRITE_SIZE" "tw_blur_solve4y<25" 16 "$out/traffic_cfg5.json" "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 tools/bench_config5.py 16 2 (tools/final_profile.sh)" > "$out/traffic_cfg5.log" 2>&1
+# ... and what really holds that launch: VALU issue share + shader clock (one SQ pass; merged into traffic_cfg5.json as `_valu`)
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_CVT GRBM_GUI_ACTIVE --output-format csv -d "$out/pmc5_VALU" -o run -- python3 tools/bench_config5.py 16 2 > "$out/pmc5_VALU.log" 2>&1
+python3 tools/pmc_valu.py "$out/pmc5_VALU" "$out/valu_cfg5.json" "tw_blur_solve4y<25" "tw_blur_solve8<25:packed" > "$out/valu_cfg5.log" 2>&1
+python3 - "$out" <<'PY'
+import json, sys, os
+d = sys.argv[1]
+try:
+    t = json.load(open(os.path.join(d, "traffic_cfg5.json"))); v = json.load(open(os.path.join(d, "valu_cfg5.json")))
+    if v.get("tw_blur_solve4y<25"):
+        t["_valu"] = v["tw_blur_solve4y<25"]
+        json.dump(t, open(os.path.join(d, "traffic_cfg5.json"), "w"), indent=1)
+except Exception as e:
+    print("no _valu for config 5:", e)
+PY
 python3 tools/clock_watch.py "$out/clock_power.json" -- python3 bench.py --steps 40 --warmup 4 --no-cpu-baseline --no-extras > "$out/clock_power.log" 2>&1
 python3 tools/latency.py 40 > "$out/latency.txt" 2>&1
 echo "two-stream schedule (TW_LAT_FUSED=0):" >> "$out/latency.txt"; TW_LAT_FUSED=0 python3 tools/latency.py 40 >> "$out/latency.txt" 2>&1
