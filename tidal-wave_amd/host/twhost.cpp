@@ -878,8 +878,9 @@ void Consumer::run()
         const long total = (long)req_.size() + (shared_ ? shared_->inflight.load() : own_inflight());
         return (total + (long)n_consumers_ - 1) / (long)n_consumers_;
     };
+    static const long fair_slack = getenv("TW_FAIR_SLACK") ? atol(getenv("TW_FAIR_SLACK")) : 0;
     for (;;) {
-        for (long own = own_inflight(); own > 0 && own >= fair_share() + (long)batch_ / 8; own = own_inflight()) {
+        for (long own = own_inflight(); own > 0 && own >= fair_share() + fair_slack; own = own_inflight()) {
             if (!prev2.empty()) finish_all(prev2);
             else finish_all(prev);
         }
@@ -910,9 +911,16 @@ void Consumer::run()
         // a consumer takes at most its share of what is queued, so that a short queue is spread over all GPUs
         // (a greedy grab of `batch` jobs starves the other consumers)
         // (its share of the queue alone, and — above — of everything that is left including what the engines still hold)
-        const size_t share = (req_.size() + 1 + (size_t)n_consumers_ - 1) / (size_t)n_consumers_;
-        const long room = fair_share() + 1 - own_inflight();
-        const size_t take = std::max<size_t>(1, std::min<size_t>({(size_t)batch_, share, (size_t)std::max(1L, room)}));
+        // (round 6: the share of the QUEUE ALONE is no longer a limit of its own.  With it a burst of 2 048 jobs on 8 consumers
+        // was handed out as 128, 127, 128, 127, ... and then 1/8 of whatever was left — 112, 98, 85, 49, 42, 25, 21, ... 2, 1,
+        // 1, 1: three consumers ended 20 % short of their 256 and one of them worked the tail off in 30 batches of a few
+        // pairs.  The fair share of EVERYTHING that is left already spreads a short queue: 10 jobs on 8 consumers are 2 each.)
+        const long room = fair_share() + fair_slack - own_inflight();
+        const size_t take = std::max<size_t>(1, std::min<size_t>((size_t)batch_, (size_t)std::max(1L, room)));
+        static const bool debug_takes = getenv("TW_DEBUG_TAKES") != nullptr;  // diagnostic: who takes what, when
+        if (debug_takes)
+            fprintf(stderr, "take t=%.3f ms consumer %d queue %zu inflight %ld own %ld share %ld -> take %zu\n", (double)(steady_ns() % 10000000000LL) * 1e-6,
+                    id_, req_.size(), shared_ ? shared_->inflight.load() : -1L, own_inflight(), fair_share(), take);
         Request more;
         while (jobs.size() < take && req_.tryPopNow(more)) {
             jobs.emplace_back();
