@@ -73,6 +73,10 @@ __device__ __forceinline__ float bload(__amdgpu_buffer_rsrc_t r, unsigned voff, 
 }
 typedef float __attribute__((ext_vector_type(2))) f32x2;
 typedef unsigned __attribute__((ext_vector_type(2))) u32x2;
+__device__ __forceinline__ void bstore(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float v)
+{
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
+}
 __device__ __forceinline__ f32x2 bload2(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
 {
     return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
@@ -2153,6 +2157,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             yb1 = a.beta[2 * yc + 1];
         }
     };
+    const __amdgpu_buffer_rsrc_t rsp = make_rsrc(UPS ? (const void*)prev : (const void*)R0);  // UPS: the coarser level's flow
+    const unsigned prev_p1 = UPS ? (unsigned)(a.pfps * 4) : 0u, sxb = (unsigned)sx * 4u, sx1b = (unsigned)sx1 * 4u;
+    const __amdgpu_buffer_rsrc_t rsf = make_rsrc(MODE == 0 ? (const void*)fin : (const void*)R0);  // the input flow's two planes
+    const unsigned fin_p1 = (unsigned)(a.fps_in * 4);
     auto flow_issue = [&](int k, FlowIn& f) {
         const int yc = row_of(k);
         if constexpr (UPS) {
@@ -2161,22 +2169,21 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                          : "=&v"(sy), "=&v"(f.b0), "=&v"(f.b1)
                          : "v"(ysy), "v"(yb0), "v"(yb1));
             const int r0 = clampi(sy, 0, a.ph - 1), r1 = clampi(sy + 1, 0, a.ph - 1);
-            const float* P0 = prev + (long long)r0 * a.pld;
-            const float* P1 = prev + (long long)r1 * a.pld;
-            f.p[0] = P0[sx];
-            f.p[1] = P0[sx1];
-            f.p[2] = P1[sx];
-            f.p[3] = P1[sx1];
-            f.p[4] = P0[a.pfps + sx];
-            f.p[5] = P0[a.pfps + sx1];
-            f.p[6] = P1[a.pfps + sx];
-            f.p[7] = P1[a.pfps + sx1];
+            const unsigned b0 = (unsigned)(r0 * a.pld) * 4u, b1 = (unsigned)(r1 * a.pld) * 4u;
+            f.p[0] = bload(rsp, b0 + sxb, 0u);
+            f.p[1] = bload(rsp, b0 + sx1b, 0u);
+            f.p[2] = bload(rsp, b1 + sxb, 0u);
+            f.p[3] = bload(rsp, b1 + sx1b, 0u);
+            f.p[4] = bload(rsp, b0 + sxb, prev_p1);
+            f.p[5] = bload(rsp, b0 + sx1b, prev_p1);
+            f.p[6] = bload(rsp, b1 + sxb, prev_p1);
+            f.p[7] = bload(rsp, b1 + sx1b, prev_p1);
         } else if constexpr (MODE == 2) {
             f.p[0] = f.p[1] = 0.f;
         } else {
-            const long long o = (long long)yc * a.ld + xc;
-            f.p[0] = fin[o];
-            f.p[1] = fin[o + a.fps_in];
+            const unsigned o = (unsigned)(yc * a.ld + xc) * 4u;  // (planes are below 4 GiB: check_dims)
+            f.p[0] = bload(rsf, o, 0u);
+            f.p[1] = bload(rsf, o, fin_p1);
         }
     };
     auto flow_value = [&](const FlowIn& f, float& dx, float& dy) {
@@ -2228,9 +2235,15 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     // pixel: the memory pipe's cost is per wave-instruction — ~11.6 cycles each when it is the only thing running)
     typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
     typedef const f32x2u __attribute__((address_space(1))) * gptr_c2u;
+    // (round 6: raw buffer loads — one resource for R1, the plane as a scalar byte offset, the lane's 32-bit offset as it is:
+    // the global form added the offset to the plane base with a 64-bit VALU add per load, ten per pixel)
+    const __amdgpu_buffer_rsrc_t rs1 = make_rsrc(R1);
+    unsigned r1off[5];
+#pragma unroll
+    for (int ch = 0; ch < 5; ch++) r1off[ch] = (unsigned)((long long)ch * a.ps * 4);
     auto gather_plane = [&](int ch, UpdTaps& T) {
-        const f32x2u t01 = *(gptr_c2u)((gptr_cc)r1b[ch] + go0);
-        const f32x2u t23 = *(gptr_c2u)((gptr_cc)r1b[ch] + go1);
+        const f32x2 t01 = bload2(rs1, go0, r1off[ch]);
+        const f32x2 t23 = bload2(rs1, go1, r1off[ch]);
         T.t[ch][0] = t01.x;
         T.t[ch][1] = t01.y;
         T.t[ch][2] = t23.x;
@@ -2287,15 +2300,17 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     const bool sth = sitem >= 0;
     const int sr = sth ? sitem / OUT : 0, sc = sth ? sitem - sr * OUT : 0;
     const int sxo = bx * OUT + sc;
+    const __amdgpu_buffer_rsrc_t rso = make_rsrc(fout);
+    const unsigned fout_p1 = (unsigned)(a.fps_out * 4);
     auto s_phase = [&](int st, int s0) {
         const int sy = ys + st * TH + sr;
         if (sth && sxo < a.w && sy < a.h && !TW_FI_SKIP(8)) {
             const double g11 = blk[s0][0][sr][sc], g12 = blk[s0][1][sr][sc], g22 = blk[s0][2][sr][sc],
                          h1 = blk[s0][3][sr][sc], h2 = blk[s0][4][sr][sc];
             const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
-            const long long o = (long long)sy * a.ld + sxo;
-            fout[o] = (float)((g11 * h2 - g12 * h1) * idet);
-            fout[o + a.fps_out] = (float)((g22 * h1 - g12 * h2) * idet);
+            const unsigned o = (unsigned)(sy * a.ld + sxo) * 4u;
+            bstore(rso, o, 0u, (float)((g11 * h2 - g12 * h1) * idet));
+            bstore(rso, o, fout_p1, (float)((g22 * h1 - g12 * h2) * idet));
         }
     };
 
