@@ -20,35 +20,12 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 python3 tools/pmc_traffic.py "$out/pmc_FETCH_SIZE" "$out/pmc_WRITE_SIZE" "$out/traffic.json" "$out/pmc_hbm_traffic.md"
 tools/sq_probe.sh "$out/sq_polyexp" 8 1 0 > "$out/sq_polyexp.txt" 2>&1
-TW_POLYEXP_F32=1 tools/sq_probe.sh "$out/sq_polyexp_f32" 8 1 0 > "$out/sq_polyexp_f32.txt" 2>&1
-TW_POLYEXP_F32=2 tools/sq_probe.sh "$out/sq_polyexp_f32f" 8 1 0 > "$out/sq_polyexp_f32f.txt" 2>&1
-tools/sq_probe.sh "$out/sq_blur_fused" 8 3 0 0 > "$out/sq_blur_fused.txt" 2>&1
 tools/sq_probe.sh "$out/sq_flow_iter" 8 3 0 4 > "$out/sq_flow_iter.txt" 2>&1
 tools/sq_probe.sh "$out/sq_flow_iter_ups" 8 3 0 8 > "$out/sq_flow_iter_ups.txt" 2>&1
 python3 tools/sq_report.py "$out/sq_polyexp" "tw_polyexp_pk<7, 8, 0>" 265420800 "tw_polyexp_pk<7,8> @ level 0, 64 pairs (128 images of 1920x1080) per launch" packed > "$out/polyexp_sq.md"
-python3 tools/sq_report.py "$out/sq_blur_fused" tw_blur_solve4 132710400 "tw_blur_solve4<15,256,16,8> fused with the matrix refresh @ level 0, 64 pairs per launch (TW_MFREE=0's kernel; what tw_flow_iter replaces)" > "$out/blur_fused_sq.md"
 python3 tools/sq_report.py "$out/sq_flow_iter" "tw_flow_iter<15, 0" 132710400 "tw_flow_iter<15,0> (one whole iteration, no M in HBM) @ level 0, 64 pairs per launch" > "$out/flow_iter_sq.md"
 python3 tools/sq_report.py "$out/sq_flow_iter_ups" "tw_flow_iter<15, 1" 132710400 "tw_flow_iter<15,1> (first iteration of a level: flow upsample fused) @ level 0, 64 pairs per launch" > "$out/flow_iter_ups_sq.md"
 python3 tools/fi_stamps.py 4 > "$out/flow_iter_stamps.txt" 2>&1
-# same-lease A/B of the round's two default changes (two runs each, alternating)
-for i in 1 2; do for f in 0 1; do
-  TW_MFREE=$f timeout -k 10 200 python3 bench.py --steps 10 --warmup 2 --no-extras --no-cpu-baseline 2>/dev/null | grep '^{' | tail -1 > "$out/ab_mfree${f}_$i.json"
-done; done
-for i in 1 2; do for f in 0 1; do
-  TW_PYR_FUSED=$f timeout -k 10 200 python3 bench.py --steps 10 --warmup 2 --no-extras --no-cpu-baseline 2>/dev/null | grep '^{' | tail -1 > "$out/ab_pyrfused${f}_$i.json"
-done; done
-python3 - "$out" > "$out/ab_summary.txt" <<'PY'
-import json, sys, glob, os
-for key in ("mfree", "pyrfused"):
-    for f in (0, 1):
-        vals = []
-        for p in sorted(glob.glob(os.path.join(sys.argv[1], "ab_%s%d_*.json" % (key, f)))):
-            try:
-                d = json.loads(open(p).read()); vals.append((d["value"], d["roofline"]["avg_launch_us"] if d.get("roofline") else None))
-            except Exception as e:
-                vals.append(("error", str(e)))
-        print(key, "=", f, vals)
-PY
 # BASELINE config 5 (4K, 51-tap window): HBM traffic of its level-0 window launch
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$out/pmc5_$c" -o run -- python3 tools/bench_config5.py 16 2 > "$out/pmc5_$c.log" 2>&1
@@ -73,5 +50,4 @@ python3 tools/latency.py 40 > "$out/latency.txt" 2>&1
 echo "two-stream schedule (TW_LAT_FUSED=0):" >> "$out/latency.txt"; TW_LAT_FUSED=0 python3 tools/latency.py 40 >> "$out/latency.txt" 2>&1
 timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d "$out/lat_trace" -o run -- python3 tools/latency.py 10 1 > "$out/lat_trace.log" 2>&1
 python3 tools/timeline.py "$out/lat_trace" 23 > "$out/lat_timeline.txt" 2>&1
-python3 tools/polyexp_f32.py > "$out/polyexp_f32.json" 2> "$out/polyexp_f32.err"
 echo done; cut -c1-400 "$out/bench.json"
