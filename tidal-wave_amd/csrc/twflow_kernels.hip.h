@@ -2097,6 +2097,34 @@ template <int MH, int MODE, int NT = 1024>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void tw_flow_iter(FlowIterArgs a)
 {
     constexpr bool UPS = MODE == 1;
+    // DEEP (round 6; TW_FI_DEEP, default on for MODE 0 / 2): the 2x2 taps of R1 are consumed ONE STEP LATER than they are
+    // issued — two tap register sets that swap roles like the two R0 sets did.  A chunk's taps then have a whole step
+    // (~9 000 cycles) to arrive and may be issued in ANY phase, phase B2 included; before, all of them had to go out in phases
+    // A and H of the step whose B2 combines them (195 of a step's 255 wave-loads in phase A alone).  R0 is loaded in the step
+    // that uses it.  The upsampling first iteration (MODE 1) carries eight coarse taps per pixel as well and keeps the old
+    // schedule: a second tap set does not fit its registers.
+#ifndef TW_FI_DEEP
+#define TW_FI_DEEP 1
+#endif
+    constexpr bool DEEP = TW_FI_DEEP && MODE != 1 && NT == 1024;
+    // where the five tap planes of the next chunk go out (DEEP): phase 0 = behind V's row `slot`, 1 = behind H's pixel `slot`,
+    // 2 = phase B2 before the combine.  TW_FI_DIST picks a preset (A/B builds).
+#ifndef TW_FI_DIST
+#define TW_FI_DIST 0
+#endif
+    // ten tap loads (plane, half) -> phase * 8 + slot: phase 0 behind V's row `slot`, 1 behind H's pixel `slot`, 2 phase B2 (slot
+    // 0 before the combine, 1 behind it).  Measured (gpurun_out/r6i, level 0, 64 pairs per launch, us per pair; the schedule
+    // without DEEP 40.85 / 41.82 on the two leases): preset 0 40.15 / 41.12;  1 (one load per slot, every phase) 41.13;  all ten
+    // in phase B2 44.8;  all ten in phase A 42.9;  four more spreadings within +-0.2 % of preset 0.  A burst of loads in one phase
+    // blocks its waves at the issue; beyond avoiding that the placement does not matter.
+#define TW_FI_P(ph, sl) ((ph) * 8 + (sl))
+    constexpr int DIST[4][10] = {
+        // plane 0 (row y1, row y1 + 1), plane 1, plane 2, plane 3, plane 4
+        {TW_FI_P(0, 0), TW_FI_P(0, 0), TW_FI_P(1, 0), TW_FI_P(1, 0), TW_FI_P(1, 1), TW_FI_P(1, 1), TW_FI_P(2, 0), TW_FI_P(2, 0), TW_FI_P(2, 0), TW_FI_P(2, 0)},
+        {TW_FI_P(0, 1), TW_FI_P(0, 3), TW_FI_P(1, 0), TW_FI_P(1, 1), TW_FI_P(1, 2), TW_FI_P(1, 3), TW_FI_P(2, 0), TW_FI_P(2, 0), TW_FI_P(2, 1), TW_FI_P(2, 1)},
+        {TW_FI_P(2, 0), TW_FI_P(2, 0), TW_FI_P(2, 0), TW_FI_P(2, 0), TW_FI_P(2, 0), TW_FI_P(2, 0), TW_FI_P(2, 0), TW_FI_P(2, 0), TW_FI_P(2, 0), TW_FI_P(2, 0)},
+        {TW_FI_P(0, 0), TW_FI_P(0, 0), TW_FI_P(0, 1), TW_FI_P(0, 1), TW_FI_P(0, 2), TW_FI_P(0, 2), TW_FI_P(0, 3), TW_FI_P(0, 3), TW_FI_P(0, 4), TW_FI_P(0, 4)},
+    };
     constexpr int TH = FI_TH, SC = NT == 1024 ? FI_SC : FI_SC_512, P = NT == 1024 ? FI_PITCH : FI_PITCH_512, OUT = SC - 2 * MH,
                   RING = TH + 2 * MH, NCH = RING / TH, NB = NCH + 1;
     static_assert(RING % TH == 0 && SC <= P && TH * SC <= NT && TH == 5 && OUT % 4 == 0 && 5 * TH * (OUT / 4) <= NT && (NB & (NB - 1)) == 0, "geometry");
@@ -2249,6 +2277,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         T.t[ch][2] = t23.x;
         T.t[ch][3] = t23.y;
     };
+    // one of a plane's two 8-byte loads (half 0: the row of y1, half 1: the row below)
+    auto gather_half = [&](int ch, int half, UpdTaps& T) {
+        if (TW_FI_SKIP(32) && ch >= 3) return;  // (timing experiment: 6 instead of 10 tap loads per pixel; wrong results)
+        const f32x2 t = bload2(rs1, half ? go1 : go0, r1off[ch]);
+        T.t[ch][2 * half] = t.x;
+        T.t[ch][2 * half + 1] = t.y;
+    };
     auto gather_issue = [&](int k, float dx, float dy, float q[5], UpdTaps& T) {
         gather_head(k, dx, dy, q, T, true);
 #pragma unroll
@@ -2266,6 +2301,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     float q[5];
     UpdTaps T;
     float dx = 0.f, dy = 0.f;
+    UpdTaps Tb;                  // DEEP: the second tap set
+    float dxb = 0.f, dyb = 0.f;  // ... and its chunk's flow
     if (cth) {
         ytab_issue(0);
         flow_issue(0, fcur);
@@ -2279,8 +2316,22 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             combine_store(k, dx, dy, q, T);
             fcur = fnext;
         }
+        if constexpr (DEEP) {
+            // chunk NCH: flow -> (dx, dy), head -> T, ALL of its taps go out now (step 0 combines them);
+            // chunk NCH + 1: flow -> (dxb, dyb), head -> Tb and the tap offsets go0 / go1 (step 0 issues its taps)
+            FlowIn f2;
+            flow_issue(NCH + 1, f2);
+            ytab_issue(NCH + 2);
+            flow_value(fnext, dx, dy);
+            gather_head(NCH, dx, dy, q, T, false);
+#pragma unroll
+            for (int ch = 0; ch < 5; ch++) gather_plane(ch, T);
+            flow_value(f2, dxb, dyb);
+            gather_head(NCH + 1, dxb, dyb, q, Tb, false);
+        } else {
         flow_value(fnext, dx, dy);
         gather_head(NCH, dx, dy, q, T, true);
+        }
         // chunk NCH's flow is in dx / dy, its tap addresses are set and its R0 is in flight into q; step 0 loads the flow of
         // chunk NCH + 1 before its V and turns it into addresses in its phase B2.  From here on ONE flow
         // variable is carried: its arrived value is consumed into dx / dy, then the next load is issued into the same
@@ -2316,8 +2367,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 
     // H of one item: (plane hp, row hr, 4-pixel group hq): 36-value window of block bX, four sums into block s0; WITH_LOADS:
     // the taps of planes 3 and 4 of the thread's phase-C pixel behind the first two pixels (main waves only)
-    auto h_phase = [&](int s0, int bX, auto with_loads_c) {
+    auto h_phase = [&](int s0, int bX, auto with_loads_c, UpdTaps& Tl) {
         constexpr bool WITH_LOADS = decltype(with_loads_c)::value;
+        constexpr int HPLANE0 = DEEP ? 1 : 3;  // the tap planes that go out behind H's first two pixels
         float v[4 + 2 * MH + 2];
         const f32x4* W4 = (const f32x4*)&blk[bX][hp][hr][4 * hq];
 #pragma unroll
@@ -2340,7 +2392,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             o[j] = sum;
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (WITH_LOADS) {
-                if (j < 2) gather_plane(3 + j, T);
+                if constexpr (DEEP) {
+#pragma unroll
+                    for (int u = 0; u < 10; u++)
+                        if (DIST[TW_FI_DIST][u] == TW_FI_P(1, j)) gather_half(u >> 1, u & 1, Tl);
+                } else {
+                    if (j < 2) gather_plane(HPLANE0 + j, Tl);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -2357,7 +2415,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         for (int st = 0; st < nsteps; st++) {
             const int s0 = st & (NB - 1), bX = (st + NCH) & (NB - 1);
             TW_FI_SYNC();  // (V)
-            if (hth && !TW_FI_SKIP(4)) h_phase(s0, bX, std::false_type());
+            if (hth && !TW_FI_SKIP(4)) h_phase(s0, bX, std::false_type(), T);
             TW_FI_SYNC();  // (H)
             s_phase(st, s0);
             TW_FI_SYNC();  // (C, S)
@@ -2422,7 +2480,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         // ---- phase B1: H — (plane, row, 4-pixel group): 36-value window from block X, four sums into block Y ----
         // (every H thread of these waves issues the tap loads: the few that have no pixel in phase C load from offset 0 of
         // the plane — valid, unused — rather than make the load conditional: see above)
-        if (!TW_FI_SKIP(4)) h_phase(s0, bX, std::true_type());
+        if (!TW_FI_SKIP(4)) h_phase(s0, bX, std::true_type(), T);
         TW_FI_STAMP(3);
         TW_FI_SYNC();
         TW_FI_STAMP(4);
@@ -2445,6 +2503,82 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         TW_FI_STAMP(7);
         TW_FI_SYNC();
     };
+    // DEEP: one step.  (dxc, dyc, Tc): the chunk this step turns into M (st + NCH) — flow, fractions and ALL taps, issued a
+    // step ago;  (dxn, dyn, Tn): the chunk after it — flow and fractions known, tap offsets in go0 / go1, its taps go out
+    // during this step: plane 0 behind V's first row, planes 1, 2 behind H's first pixels, planes 3, 4 in phase B2.  The R0
+    // coefficients of chunk st + NCH go out behind V's rows, the flow of chunk st + NCH + 2 before them; at the end of the step
+    // that flow becomes (dxc, dyc, Tc) — the registers chunk st + NCH has just left — and go0 / go1.
+    auto step_deep = [&](int st, float& dxc, float& dyc, UpdTaps& Tc, float& dxn, float& dyn, UpdTaps& Tn) {
+        const bool more = st + 1 < nsteps;
+        const int s0 = st & (NB - 1), bX = (st + NCH) & (NB - 1);
+        TW_FI_STAMP(0);
+        if (cth) {
+            flow_issue(st + NCH + 2, fnext);
+            ytab_issue(st + NCH + 3);
+            gq = (unsigned)(row_of(st + NCH) * a.ld + xc) * 4u;
+            __builtin_amdgcn_sched_barrier(0);
+            float wv[RING];
+#pragma unroll
+            for (int j = 0; j < NCH; j++) {
+                const float* bj = &blk[(s0 + j) & (NB - 1)][cr][0][cc];
+#pragma unroll
+                for (int r = 0; r < TH; r++) wv[TH * j + r] = bj[r * P];
+            }
+            float* vout = &blk[bX][cr][0][cc];
+#pragma unroll
+            for (int r = 0; r < TH; r++) {
+                float sv = wv[r + MH] * c.k[0];
+#pragma unroll
+                for (int i = 1; i <= MH; i++) sv += (wv[r + MH + i] + wv[r + MH - i]) * c.k[i];
+                vout[r * P] = sv;
+                __builtin_amdgcn_sched_barrier(0);
+                gather_r0(r, q);                  // (R0 plane r of chunk st + NCH: this step's phase B2 combines it)
+#pragma unroll
+                for (int u = 0; u < 10; u++)
+                    if (DIST[TW_FI_DIST][u] == TW_FI_P(0, r)) gather_half(u >> 1, u & 1, Tn);  // (taps of chunk st + NCH + 1)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        TW_FI_STAMP(1);
+        TW_FI_SYNC();
+        TW_FI_STAMP(2);
+        if (!TW_FI_SKIP(4)) h_phase(s0, bX, std::true_type(), Tn);
+        TW_FI_STAMP(3);
+        TW_FI_SYNC();
+        TW_FI_STAMP(4);
+        s_phase(st, s0);
+        __builtin_amdgcn_sched_barrier(0);
+        TW_FI_STAMP(5);
+        if (cth) {
+#pragma unroll
+            for (int u = 0; u < 10; u++)
+                if (DIST[TW_FI_DIST][u] == TW_FI_P(2, 0)) gather_half(u >> 1, u & 1, Tn);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more && !TW_FI_SKIP(1)) combine_store(st + NCH, dxc, dyc, q, Tc);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 10; u++)
+                if (DIST[TW_FI_DIST][u] == TW_FI_P(2, 1)) gather_half(u >> 1, u & 1, Tn);
+            __builtin_amdgcn_sched_barrier(0);
+            TW_FI_STAMP(6);
+            // chunk st + NCH + 2: flow value, fractions and tap offsets — into the registers chunk st + NCH has left
+            flow_value(fnext, dxc, dyc);
+            gather_head(st + NCH + 2, dxc, dyc, q, Tc, false);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        TW_FI_STAMP(7);
+        TW_FI_SYNC();
+    };
+    if constexpr (DEEP) {
+        int st = 0;
+#pragma unroll 1
+        for (; st + 1 < nsteps; st += 2) {
+            step_deep(st, dx, dy, T, dxb, dyb, Tb);
+            step_deep(st + 1, dxb, dyb, Tb, dx, dy, T);
+        }
+        if (st < nsteps) step_deep(st, dx, dy, T, dxb, dyb, Tb);
+        return;
+    }
     float q1[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
     {
         int st = 0;
