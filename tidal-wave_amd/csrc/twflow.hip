@@ -414,6 +414,7 @@ struct tw_engine {
     size_t lat_cap = 0;  // floats in lat_I (lat_R holds 5x)
     std::vector<hipEvent_t> lat_ev;
     int lat_s2_max = 1000;  // TW_LAT_S2_LEVELS: finest..this level's image-only work goes to the second stream
+    int fi_maxseg = 4, fi_minsteps = 16;  // TW_FI_MAXSEG / TW_FI_MINSTEPS: most row segments per strip / fewest steps per segment (A/B)
     int fi_skip = 0;    // TW_FI_SKIP (variants library): timing experiments on tw_flow_iter (results are wrong)
     int fi_nt = 1024;   // TW_FI_NT=512 (variants library): tw_flow_iter as two 512-thread workgroups per CU on 64-output strips (A/B)
     int lat_fused = 1;  // TW_LAT_FUSED=0: the two-stream single-pair schedule of rounds 2-4 instead of the twin launches (A/B)
@@ -1197,9 +1198,9 @@ void launch_flow_iter(tw_engine* e, hipStream_t st, int w, int h, int ld, long l
     // (rounds x (steps + warm-up)) — 128 pairs x 12 strips of 1080p: 2 segments = 12.0 rounds of 108 + 7 steps.
     int best_seg = 1;
     double best_cost = 1e300;
-    for (int sg = 1; sg <= 4; sg++) {
+    for (int sg = 1; sg <= e->fi_maxseg; sg++) {
         const int nt = (nsteps + sg - 1) / sg;
-        if (sg > 1 && nt < 16) break;
+        if (sg > 1 && nt < e->fi_minsteps) break;
         const long long wgs = (long long)nstrips * sg * npairs;
         const long long rounds = (wgs + slots - 1) / slots;
         const double cost = (double)rounds * (nt + 7 * 0.25);  // a warm-up chunk is a quarter of a step (phase C only)
@@ -2384,6 +2385,8 @@ tw_status tw_engine_create(int device, const tw_params* params, int slots, tw_en
     if (const char* ev = getenv("TW_FI_SKIP")) e->fi_skip = atoi(ev);
 #endif
     if (const char* ev = getenv("TW_LAT_S2_LEVELS")) e->lat_s2_max = atoi(ev);
+    if (const char* ev = getenv("TW_FI_MAXSEG")) e->fi_maxseg = std::min(64, std::max(1, atoi(ev)));
+    if (const char* ev = getenv("TW_FI_MINSTEPS")) e->fi_minsteps = std::max(2, atoi(ev));
     // the main stream carries the dependent flow chain: highest priority, so that its small launches are not queued
     // behind the second stream's image-only work
     int prio_lo = 0, prio_hi = 0;
