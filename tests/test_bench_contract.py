@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_committed_bench_line_has_the_contract_keys():
-    d = json.load(open(os.path.join(ROOT, "profiles", "r04_bench.json")))
+    d = json.load(open(os.path.join(ROOT, "profiles", "r06_bench.json")))
     base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
     assert d["metric"] == base["metric"] and d["unit"] == "pairs/s" and d["higher_is_better"] is True
     for k in ("value", "n_gpus", "steps", "warmup", "ms_per_step", "scaling", "vs_baseline", "dtype", "data", "config"):
@@ -28,6 +28,8 @@ def test_committed_bench_line_has_the_contract_keys():
         # traffic is per launch like achieved: same pairs per launch, and never far below the as-built bytes
         assert r["traffic_pairs_per_launch"] == round(r["pairs_per_launch"])
         assert 0.95 < r["traffic"] / r["algorithmic_bytes_per_launch"] < 1.25
+        # round 6: the line says what the counters say holds the kernel — VALU issue, from a live SQ pass of the same run
+        assert r["limiter"].startswith("valu_issue") and 0.3 < r["valu_issue_frac"] <= 1.0 and 1.0 < r["shader_clock_GHz"] < 2.6
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
@@ -55,6 +57,7 @@ def test_committed_bench_line_has_the_contract_keys():
     assert c3["pairs"] >= 2048 and c3["engine_batch"] == 128 and c3["steady_state_pairs_per_s"] > c3["pairs_per_s"] > 0
     c5 = d["config5_4k"]
     assert c5["pairs"] >= 64 and c5["distinct_pairs"] >= 4 and 0.1 < c5["roofline_cfg5"]["frac"] < 1.0
+    assert c5["roofline_cfg5"]["limiter"].startswith("valu_issue") and 0.3 < c5["roofline_cfg5"]["valu_issue_frac"] <= 1.0
     assert d["files_e2e"]["pairs_per_s"] >= 1800 and d["files_e2e"]["errors"] == 0  # VERDICT r3 #6, 16 decode threads
     pv = d["polyexp_f32_variant"]
     assert 0.3 < pv["frac"] < 0.6 and pv["max_abs_flow_err"] > 1e-3 and pv["vectors_identical"] is False
