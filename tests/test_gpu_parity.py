@@ -554,6 +554,28 @@ def test_scan_fused_final_iteration_option(twflow, oracle, golden):
         assert e.diff(a, b, 10, 1.0)["vector"] == oracle.span_scan(wx, wy, 10, 1.0)
 
 
+def test_batch_path_on_a_two_level_plan(twflow, oracle, golden):
+    """the batch path (flush_ctx) on plans with FEWER than four pyramid levels — the reference's 180x117 fixture has
+    two (90x58 and 180x117), a 64x64 image two, a 40x40 one a single level: the level-3 / level-2 pyramid fusion must not even
+    look at levels such a plan does not have.  Three pairs per batch, vectors against the oracle."""
+    c = golden["revision2_capture2"]
+    rng = np.random.default_rng(12)
+    cases = [(c["expect_img"], c["target_img"])]
+    for (h, w) in ((64, 64), (40, 40)):
+        a = rand_img(rng, h, w)
+        cases.append((a, np.roll(a, 1, axis=1)))
+    for a, b in cases:
+        wx, wy = oracle.farneback(a, b)
+        want = oracle.span_scan(wx, wy, 10, 0.0)
+        with twflow.Engine(0, twflow.default_params(), slots=4) as e:
+            assert e.num_levels(a.shape[1], a.shape[0]) < 3
+            tk = [e.submit(a, b, 10, 0.0) for _ in range(3)]
+            for t in tk:
+                assert e.wait(t)["vector"] == want, a.shape
+            cnt = e.launch_counts()
+            assert cnt["tw_pyr_23"] == 0 and cnt.flow_iter() == 0, cnt
+
+
 def test_pipeline_with_every_round5_fusion_forced(twflow, oracle):
     """TW_MFREE=2 (tw_flow_iter for every launch of an eligible level): batches of 640x480 and 646x482 pairs then run
     tw_pyr_k3f (levels 0 + 1 from one read, level 0's images parked in the M1 region), tw_pyr_23 and tw_flow_iter together;

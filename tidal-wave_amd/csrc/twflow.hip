@@ -1437,7 +1437,10 @@ void launch_blur(tw_engine* e, hipStream_t st, int w, int h, int ld, long long p
 #endif
         // wide levels: two vertically adjacent 8-row sub-tiles share one 66-row register window (round 3: -7 % against the
         // one-sub-tile kernel with its 58-row window per 8 rows, which TW_BLUR_VARIANT=41 of the variants library selects)
-        if (wide) TW_LAUNCH(e, TW_DF_BLUR_SOLVE4Y, (tw_blur_solve4y<25, 256, 32, 8, 2>), dim3((w + 191) / 192, (h + 15) / 16, npairs), dim3(256), 0, st, a);
+#ifndef TW_4Y_ILP  // (A/B builds: vertical / horizontal interleave and solve unroll of the 51-tap kernel)
+#define TW_4Y_ILP 2, 2, 2
+#endif
+        if (wide) TW_LAUNCH(e, TW_DF_BLUR_SOLVE4Y, (tw_blur_solve4y<25, 256, 32, 8, 2, TW_4Y_ILP>), dim3((w + 191) / 192, (h + 15) / 16, npairs), dim3(256), 0, st, a);
         else TW_LAUNCH(e, TW_DF_BLUR_SOLVE8, (tw_blur_solve8<25, 128, 32, 8, true, false>), dim3((w + 63) / 64, gy, npairs), dim3(128), 0, st, a);
     } else {
         // any other window size: generic kernel (same arithmetic, runtime loops)

@@ -1523,13 +1523,18 @@ __device__ __forceinline__ void update_matrices_gather(const float* __restrict__
     T.fx = fx - (float)x1;
     T.fy = fy - (float)y1;
     T.inb = inb;
-    const float* p = R1 + (long long)y1 * ld + x1;
+    // (round 6: raw buffer loads — R1's five planes behind one resource, the plane a scalar byte offset, the lane's position a
+    // 32-bit one; the pointer form cost a 64-bit VALU add per plane and row.  The two taps of a row as one 8-byte load.)
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(R1);
+    const unsigned o0 = (unsigned)(y1 * ld + x1) * 4u, o1 = o0 + (unsigned)ld * 4u;
 #pragma unroll
     for (int c = 0; c < 5; c++) {
-        T.t[c][0] = p[c * ps];
-        T.t[c][1] = p[c * ps + 1];
-        T.t[c][2] = p[c * ps + ld];
-        T.t[c][3] = p[c * ps + ld + 1];
+        const unsigned so = (unsigned)(c * ps * 4);
+        const f32x2 t01 = bload2(rs, o0, so), t23 = bload2(rs, o1, so);
+        T.t[c][0] = t01.x;
+        T.t[c][1] = t01.y;
+        T.t[c][2] = t23.x;
+        T.t[c][3] = t23.y;
     }
 }
 // The same gather with wave-uniform plane bases in SGPR pairs and ONE 32-bit byte offset per lane and pixel (planes are
@@ -1620,8 +1625,10 @@ __device__ __forceinline__ void update_matrices_px(const float* __restrict__ R0,
                                                    long long ps, int ld, int w, int h, int x, int y, float dx,
                                                    float dy, float M[5])
 {
-    const long long o = (long long)y * ld + x;
-    const float q[5] = {R0[o], R0[o + ps], R0[o + 2 * ps], R0[o + 3 * ps], R0[o + 4 * ps]};
+    const __amdgpu_buffer_rsrc_t rs0 = make_rsrc(R0);
+    const unsigned o = (unsigned)(y * ld + x) * 4u;
+    const float q[5] = {bload(rs0, o, 0u), bload(rs0, o, (unsigned)(ps * 4)), bload(rs0, o, (unsigned)(2 * ps * 4)),
+                        bload(rs0, o, (unsigned)(3 * ps * 4)), bload(rs0, o, (unsigned)(4 * ps * 4))};
     update_matrices_core(q, R1, ps, ld, w, h, x, y, dx, dy, M);
 }
 
@@ -1888,9 +1895,17 @@ __global__ __launch_bounds__(COLS) __attribute__((amdgpu_waves_per_eu(4, 8))) vo
                     cx = c0 >= TW ? c0 - TW : c0;
                 }
                 const int xc = clampi(x0 + cx, 0, a.w - 1), yc = min(y0 + r, a.h - 1);
+                // (round 6: 32-bit offsets behind a buffer resource unless the cache-policy A/B build wants its nontemporal loads)
+                if constexpr (((TW_NT >> 1) & 1) == 0) {
+                    const __amdgpu_buffer_rsrc_t rsR0 = make_rsrc(R0p);
+                    const unsigned o = (unsigned)(yc * a.ld + xc) * 4u;
+#pragma unroll
+                    for (int cc = 0; cc < 5; cc++) qpre[i][cc] = bload(rsR0, o, (unsigned)(cc * a.ps * 4));
+                } else {
                 const long long o = (long long)yc * a.ld + xc;
 #pragma unroll
                 for (int cc = 0; cc < 5; cc++) qpre[i][cc] = ld_stream<1>(R0p + o + cc * a.ps);
+                }
             }
         }
     }
@@ -1960,6 +1975,7 @@ __global__ __launch_bounds__(COLS) __attribute__((amdgpu_waves_per_eu(4, 8))) vo
     float* __restrict__ Mout = a.Mout + (long long)z * 5 * a.ps;
     const float* __restrict__ R0 = a.R + (long long)(2 * z) * 5 * a.ps;
     const float* __restrict__ R1 = R0 + 5 * a.ps;
+    const __amdgpu_buffer_rsrc_t rsF = make_rsrc(flow), rsM = make_rsrc(Mout);
     // Every lane always computes (on a clamped, valid pixel); only the stores are predicated, so the loop body
     // has no control flow and the gathers of SUNROLL pixels are in flight together.
 #pragma unroll
@@ -1991,9 +2007,10 @@ __global__ __launch_bounds__(COLS) __attribute__((amdgpu_waves_per_eu(4, 8))) vo
         const float fxv = (float)((g11 * h2 - g12 * h1) * idet);
         const float fyv = (float)((g22 * h1 - g12 * h2) * idet);
         const long long o = (long long)yc * a.ld + xc;
+        const unsigned ob = (unsigned)(yc * a.ld + xc) * 4u;
         if (valid && (!a.update || a.store_flow)) {
-            flow[o] = fxv;
-            flow[o + a.fps] = fyv;
+            bstore(rsF, ob, 0u, fxv);
+            bstore(rsF, ob, (unsigned)(a.fps * 4), fyv);
             if (a.gspan > 0) {  // wave-uniform
                 const unsigned qx = __umulhi((unsigned)xc, a.gmagic), qy = __umulhi((unsigned)yc, a.gmagic);
                 if (qx * (unsigned)a.gspan == (unsigned)xc && qy * (unsigned)a.gspan == (unsigned)yc)
@@ -2006,8 +2023,13 @@ __global__ __launch_bounds__(COLS) __attribute__((amdgpu_waves_per_eu(4, 8))) vo
                 if constexpr (QPRE) update_matrices_core(qpre[i], R1, a.ps, a.ld, a.w, a.h, xc, yc, fxv, fyv, M);
                 else update_matrices_px(R0, R1, a.ps, a.ld, a.w, a.h, xc, yc, fxv, fyv, M);
                 if (valid) {
+                    if constexpr ((TW_NT & 1) == 0) {
 #pragma unroll
-                    for (int cc = 0; cc < 5; cc++) st_stream<0>(Mout + o + cc * a.ps, M[cc]);
+                        for (int cc = 0; cc < 5; cc++) bstore(rsM, ob, (unsigned)(cc * a.ps * 4), M[cc]);
+                    } else {
+#pragma unroll
+                        for (int cc = 0; cc < 5; cc++) st_stream<0>(Mout + o + cc * a.ps, M[cc]);
+                    }
                 }
             }
         }
@@ -2261,8 +2283,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     };
     // the two taps of a row are adjacent: ONE 8-byte load at 4-byte alignment each (10 instead of 20 tap instructions per
     // pixel: the memory pipe's cost is per wave-instruction — ~11.6 cycles each when it is the only thing running)
-    typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
-    typedef const f32x2u __attribute__((address_space(1))) * gptr_c2u;
     // (round 6: raw buffer loads — one resource for R1, the plane as a scalar byte offset, the lane's 32-bit offset as it is:
     // the global form added the offset to the plane base with a 64-bit VALU add per load, ten per pixel)
     const __amdgpu_buffer_rsrc_t rs1 = make_rsrc(R1);
@@ -3397,6 +3417,8 @@ __global__ __launch_bounds__(COLS) __attribute__((amdgpu_waves_per_eu(4, 8))) vo
     float* __restrict__ Mout = a.Mout + (long long)z * 5 * a.ps;
     const float* __restrict__ R0 = a.R + (long long)(2 * z) * 5 * a.ps;
     const float* __restrict__ R1 = R0 + 5 * a.ps;
+    // (round 6: 32-bit offsets behind buffer resources for the solve phase's R0 loads and flow / M stores too)
+    const __amdgpu_buffer_rsrc_t rsR0 = make_rsrc(R0), rsF = make_rsrc(flow), rsM = make_rsrc(Mout);
 
     // ---- V: all sub-tiles ----
     float vlate[5][NR - TH];  // vertical results of the sub-tiles after the first
@@ -3456,9 +3478,9 @@ __global__ __launch_bounds__(COLS) __attribute__((amdgpu_waves_per_eu(4, 8))) vo
                 const int p = t + i * COLS;
                 const int r = p / TW, c0 = p - r * TW + a.rot, cx = c0 >= TW ? c0 - TW : c0;
                 const int xc = clampi(x0 + cx, 0, a.w - 1), yc = min(y0 + r, a.h - 1);
-                const long long o = (long long)yc * a.ld + xc;
+                const unsigned o = (unsigned)(yc * a.ld + xc) * 4u;
 #pragma unroll
-                for (int cc = 0; cc < 5; cc++) qpre[i][cc] = R0[o + cc * a.ps];
+                for (int cc = 0; cc < 5; cc++) qpre[i][cc] = bload(rsR0, o, (unsigned)(cc * a.ps * 4));
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -3515,10 +3537,10 @@ __global__ __launch_bounds__(COLS) __attribute__((amdgpu_waves_per_eu(4, 8))) vo
             const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
             const float fxv = (float)((g11 * h2 - g12 * h1) * idet);
             const float fyv = (float)((g22 * h1 - g12 * h2) * idet);
-            const long long o = (long long)yc * a.ld + xc;
+            const unsigned o = (unsigned)(yc * a.ld + xc) * 4u;
             if (valid && (!a.update || a.store_flow)) {
-                flow[o] = fxv;
-                flow[o + a.fps] = fyv;
+                bstore(rsF, o, 0u, fxv);
+                bstore(rsF, o, (unsigned)(a.fps * 4), fyv);
             }
             if (a.update) {  // wave-uniform
                 float M[5];
@@ -3526,7 +3548,7 @@ __global__ __launch_bounds__(COLS) __attribute__((amdgpu_waves_per_eu(4, 8))) vo
                 else update_matrices_px(R0, R1, a.ps, a.ld, a.w, a.h, xc, yc, fxv, fyv, M);
                 if (valid) {
 #pragma unroll
-                    for (int cc = 0; cc < 5; cc++) Mout[o + cc * a.ps] = M[cc];
+                    for (int cc = 0; cc < 5; cc++) bstore(rsM, o, (unsigned)(cc * a.ps * 4), M[cc]);
                 }
             }
         }
