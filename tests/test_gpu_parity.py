@@ -1184,10 +1184,11 @@ def test_host_uploads_do_not_grow_the_process(twflow):
       1. the LIBRARY's own accounting (tw_debug_memory: device bytes, page-locked bytes, plans, page-lock table, pooled
          events) must not move at all once the first batches have sized everything;
       2. glibc malloc's bytes IN USE (mallinfo2 over all arenas: every new / malloc of the library and of the HIP runtime,
-         whatever the allocator then does with the pages) must stay within 2 MB — the 1 KB-per-image leak is 10 MB here;
-      3. the resident set, coarsely (< 256 MB), with the whole series written to gpurun_out/r06_leak_trace.json so that a
-         step, if one shows again, is attributed from the record of that one run (AnonHugePages vs malloc_from_os vs
-         neither = driver mappings) instead of being hunted by re-running."""
+         whatever the allocator then does with the pages) must stay within 2 MB outside one largest interval — the 1 KB-per-image
+         leak is 10 MB here;
+      3. the resident set, without its largest interval (< 8 MB), with the whole series written to
+         gpurun_out/r06_leak_trace.json so that a step is attributed from the record of the run it happened in.  It did show
+         again, once in five full-suite runs of round 6, and the record attributes it: see the assertions below."""
     import json
     import os
     import synth
@@ -1221,10 +1222,22 @@ def test_host_uploads_do_not_grow_the_process(twflow):
         base, end = rows[0], rows[-1]
         assert all(r["engine"] == base["engine"] for r in rows), \
             "%s: the library's own accounting moved: %r -> %r" % (name, base["engine"], end["engine"])
+
+        # A LEAK keeps growing: every interval between two samples shows it.  A one-off step does not: the run recorded in
+        # profiles/r06_leak_trace_step.json has ONE — resident set +185.8 MB (177 MB of it anonymous, clean, not malloc's),
+        # malloc in use +8.4 MB, between two samples ten iterations apart, flat before, flat after, the library's books flat
+        # throughout: the HIP runtime bringing up another hardware queue for the engine's streams (its context-save area is
+        # of that size on this part), which it does lazily and at most a few times per process.  So the growth is measured
+        # WITHOUT its single largest interval: 1 KB per uploaded image is 0.64 MB in each of the 16 intervals and 9.6 MB
+        # without the largest; a one-off step is 0.
+        def growth_without_largest_step(key):
+            d = [b[key] - a[key] for a, b in zip(rows, rows[1:])]
+            return sum(d) - max(d), max(d)
         if "malloc_in_use" in base:
-            grew = end["malloc_in_use"] - base["malloc_in_use"]
-            assert grew < 2.0, "%s: malloc bytes in use grew by %.2f MB over 10 240 pairs (%r -> %r)" % (name, grew, base, end)
-        assert end["Rss"] - base["Rss"] < 256.0, "%s: resident set %r -> %r" % (name, base, end)
+            g, step = growth_without_largest_step("malloc_in_use")
+            assert g < 2.0 and step < 32.0, "%s: malloc bytes in use grew by %.2f MB (+ one step of %.2f) over 10 240 pairs" % (name, g, step)
+        g, step = growth_without_largest_step("Rss")
+        assert g < 8.0 and step < 400.0, "%s: resident set grew by %.1f MB (+ one step of %.1f) over 10 240 pairs" % (name, g, step)
 
 
 def test_out_of_memory_is_reported_and_the_engine_recovers(twflow, oracle, monkeypatch):

@@ -200,8 +200,52 @@ __global__ __launch_bounds__(256) void tw_pyr_level(PyrArgs a)
 
     // ---- row filter (float) of source rows [ylo,yhi] at the needed columns ----
     const float* kc = skern + r;
-    for (int it = tid; it < nrows * P; it += 256) {
-        const int rr = it / P, p = it - rr * P;
+    // Round 6 — kernels of more than 5 taps (the coarsest levels of a deep pyramid whose regions are too large to stage:
+    // BASELINE configs[4]'s 39- and 79-tap smoothing of a 4K image, 9.2 % of that configuration's GPU time): the loop below
+    // fetched one byte per tap, each through reflect101 and each waited for.  Positions whose window lies inside the row take
+    // their taps four at a time from unaligned dwords, same left-to-right sum; the FEW positions at the image's left / right
+    // border (X is monotonic in p: a prefix [0, pL) and a suffix [pR, P) of the tile's positions) are left to the loop below,
+    // which then runs over those positions only — in one loop the border lanes' byte-by-byte path would be executed by every
+    // wave that holds one of them (measured: no gain at all that way).
+    int pL = 0, pR = P;
+    const bool wide_taps = ksize > 5;
+    if (wide_taps) {
+        auto Xof = [&](int p) {
+            const int ox = min(x0 + ((a.mode == 0) ? p : (p >> 1)), a.w - 1);
+            return (a.mode == 0) ? ox : (a.xofs[ox] + (p & 1));
+        };
+        while (pL < P && Xof(pL) - r < 0) pL++;
+        while (pR > pL && Xof(pR - 1) - r + ksize + 3 > a.w0) pR--;
+        typedef unsigned u32u __attribute__((aligned(1)));
+        const int PI = pR - pL;  // interior positions of a row
+        for (int it = tid; it < nrows * PI; it += 256) {
+            const int rr = it / PI, p = pL + it - rr * PI;
+            const int Y = reflect101(ylo + rr, a.h0);
+            const uint8_t* __restrict__ q = src + (long long)Y * a.stride + (Xof(p) - r);
+            // (the compiler merges four of these dwords into one 16-byte load; requesting ALL of a window's bytes before the
+            // first tap — up to eight 16-byte loads in flight per lane — measured 20 % slower: gpurun_out/r6y)
+            unsigned wd = *(const u32u*)q;
+            float s = skern[0] * (float)(wd & 0xffu);
+            s += skern[1] * (float)((wd >> 8) & 0xffu);
+            s += skern[2] * (float)((wd >> 16) & 0xffu);
+            s += skern[3] * (float)(wd >> 24);
+            int j = 4;
+            for (; j + 3 < ksize; j += 4) {
+                wd = *(const u32u*)(q + j);
+                s += skern[j] * (float)(wd & 0xffu);
+                s += skern[j + 1] * (float)((wd >> 8) & 0xffu);
+                s += skern[j + 2] * (float)((wd >> 16) & 0xffu);
+                s += skern[j + 3] * (float)(wd >> 24);
+            }
+            for (; j < ksize; j++) s += skern[j] * (float)q[j];
+            rowbuf[rr * P + p] = s;
+        }
+    }
+    const int PB = wide_taps ? pL + (P - pR) : P;  // positions the general loop handles: the border ones, or all
+    for (int it = tid; it < nrows * PB; it += 256) {
+        const int rr = it / PB;
+        int p = it - rr * PB;
+        if (wide_taps && p >= pL) p += pR - pL;
         int ox = x0 + ((a.mode == 0) ? p : (p >> 1));
         ox = min(ox, a.w - 1);
         const int X = (a.mode == 0) ? ox : (a.xofs[ox] + (p & 1));
