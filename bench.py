@@ -281,7 +281,9 @@ def limiter_fields(name, traffic):
     return {"limiter": "valu_issue at a power-capped clock (not HBM: moved bytes / time is the `frac` above, traffic = 1.0 x the "
                        "algorithmic bytes)",
             "valu_issue_frac": v["valu_issue_frac"], "shader_clock_GHz": v["shader_clock_GHz"],
-            "valu_note": "live SQ pass of this run (tools/pmc_valu.py): VALU wave-instructions x measured issue cost (f32 2.2, "
+            "valu_note": ("live SQ pass of this run" if (traffic.get("_provenance") or {}).get("source", "").startswith("live")
+                          else "static: the SQ passes behind profiles/traffic_latest.json, not a counter of this run") +
+                         " (tools/pmc_valu.py): VALU wave-instructions x measured issue cost (f32 2.2, "
                          "f64-class / packed f32 4.3 cycles) / (clock cycles x 1024 SIMDs); clock = GRBM_GUI_ACTIVE / 8 / "
                          "duration under the counters (%s, %.0f us)" % (v["kernel"], v["launch_us_under_pmc"])}
 
