@@ -228,6 +228,7 @@ struct LevelPlan {
     float h_kern[3] = {0, 0, 0};  // host copy of the taps when ksize == 3
     std::vector<float> h_taps;    // host copy of all taps
     int pitch_b = 0;              // staged-row pitch (bytes) of tw_pyr_level_lds, 0: does not fit LDS
+    int gen_th = PYR_TH, gen_nrows_max = 0;  // tile height of the UNSTAGED kernel (tw_pyr_level) and its row-buffer height
     // flow upsample tables (level k+1 -> k)
     int *d_uxofs = nullptr, *d_uyofs = nullptr;
     float *d_ualpha = nullptr, *d_ubeta = nullptr;
@@ -574,11 +575,11 @@ void level_geometry(int w0, int h0, double pyr_scale, int k, int* w, int* h, dou
     *scale_out = scale;
 }
 
-int pyr_nrows_max(const ResizeTab& t, int h, int h0, int r)
+int pyr_nrows_max(const ResizeTab& t, int h, int h0, int r, int th = PYR_TH)
 {
     int mx = 0;
-    for (int y0 = 0; y0 < h; y0 += PYR_TH) {
-        const int yB = std::min(y0 + PYR_TH - 1, h - 1);
+    for (int y0 = 0; y0 < h; y0 += th) {
+        const int yB = std::min(y0 + th - 1, h - 1);
         const int ylo = std::min(std::max(t.yofs[y0], 0), h0 - 1) - r;
         const int yhi = std::min(std::max(t.yofs[yB] + 1, 0), h0 - 1) + r;
         mx = std::max(mx, yhi - ylo + 1);
@@ -679,6 +680,16 @@ tw_status get_plan(tw_engine* e, int w0, int h0, Plan** out)
         if (L.ksize == 3) memcpy(L.h_kern, kern.data(), sizeof(L.h_kern));
         L.h_taps = kern;
         L.nrows_max = pyr_nrows_max(t, L.h, h0, L.ksize / 2);
+        // Round 6: the unstaged kernel takes 4-row tiles when an 8-row tile's row buffer is more than 32 KB (a deep level of a
+        // large image: BASELINE configs[4]'s 39- / 79-tap levels of a 4K pyramid).  Twice the workgroups at 0.6 of the work
+        // each, five / three of them per CU instead of three / two, and the last round of a launch no longer a quarter full
+        // (TW_PYR_GEN_TH=8: the old tiles, A/B).
+        {
+            static const int gen_th_env = getenv("TW_PYR_GEN_TH") ? atoi(getenv("TW_PYR_GEN_TH")) : 0;
+            const size_t rb8 = (size_t)L.nrows_max * (t.mode == 0 ? PYR_TW : 2 * PYR_TW) * 4;
+            L.gen_th = gen_th_env >= 1 && gen_th_env <= PYR_TH ? gen_th_env : (rb8 > 32 * 1024 ? 4 : PYR_TH);
+            L.gen_nrows_max = L.gen_th == PYR_TH ? L.nrows_max : pyr_nrows_max(t, L.h, h0, L.ksize / 2, L.gen_th);
+        }
         const size_t lds = (size_t)(PYR_MAXK + (size_t)L.nrows_max * (t.mode == 0 ? PYR_TW : 2 * PYR_TW)) * 4;
         if (lds > 160 * 1024) {
             e->err = "pyramid tile does not fit LDS (scale/kernel too large)";
@@ -941,6 +952,7 @@ void launch_pyr(tw_engine* e, hipStream_t st, const Plan* pl, int k, const uint8
     a.mode = L.mode;
     a.xmax = L.xmax;
     a.nrows_max = L.nrows_max;
+    a.th = PYR_TH;
     const int P = (L.mode == 0) ? PYR_TW : 2 * PYR_TW;
     const size_t lds = (size_t)(PYR_MAXK + (size_t)L.nrows_max * P) * 4;
     dim3 grid((L.w + PYR_TW - 1) / PYR_TW, (L.h + PYR_TH - 1) / PYR_TH, nimg);
@@ -990,7 +1002,13 @@ void launch_pyr(tw_engine* e, hipStream_t st, const Plan* pl, int k, const uint8
         TW_LAUNCH(e, TW_DF_PYR_LEVEL, tw_pyr_level_lds, grid, dim3(256), lds + (size_t)L.nrows_max * L.pitch_b, st, b);
         return;
     }
-    TW_LAUNCH(e, TW_DF_PYR_LEVEL, tw_pyr_level, grid, dim3(256), lds, st, a);
+    {
+        a.th = L.gen_th;
+        a.nrows_max = L.gen_nrows_max;
+        const size_t lds_g = (size_t)(PYR_MAXK + (size_t)L.gen_nrows_max * P) * 4;
+        const dim3 grid_g((L.w + PYR_TW - 1) / PYR_TW, (L.h + L.gen_th - 1) / L.gen_th, nimg);
+        TW_LAUNCH(e, TW_DF_PYR_LEVEL, tw_pyr_level, grid_g, dim3(256), lds_g, st, a);
+    }
 }
 
 // levels 3 and 2 of `nimg` images from one read of each image (tw_pyr_23; pl->fused23): I3 / I2 = the level images,

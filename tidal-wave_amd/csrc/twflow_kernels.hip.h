@@ -177,6 +177,7 @@ struct PyrArgs {
     int mode;  // 0: same size (identity resize), 1: INTER_LINEAR, 2: 2x2 INTER_AREA fast path
     int xmax;  // dx >= xmax: single-tap columns (HResizeLinear tail loop)
     int nrows_max;
+    int th;    // tw_pyr_level only: output rows per tile (PYR_TH, or 4 for the deep levels of a large image)
 };
 
 __global__ __launch_bounds__(256) void tw_pyr_level(PyrArgs a)
@@ -185,14 +186,14 @@ __global__ __launch_bounds__(256) void tw_pyr_level(PyrArgs a)
     float* skern = pyr_sm;               // [PYR_MAXK]
     float* rowbuf = pyr_sm + PYR_MAXK;   // [nrows][P]
     const int tid = threadIdx.x;
-    const int x0 = blockIdx.x * PYR_TW, y0 = blockIdx.y * PYR_TH;
+    const int x0 = blockIdx.x * PYR_TW, y0 = blockIdx.y * a.th;
     const uint8_t* __restrict__ src = a.srcs[blockIdx.z];
     float* __restrict__ dst = a.dst + blockIdx.z * a.dst_zs;
     const int ksize = a.ksize, r = ksize >> 1;
     const int P = (a.mode == 0) ? PYR_TW : 2 * PYR_TW;
 
     if (tid < ksize) skern[tid] = a.kern[tid];
-    const int yA = y0, yB = min(y0 + PYR_TH - 1, a.h - 1);
+    const int yA = y0, yB = min(y0 + a.th - 1, a.h - 1);
     const int ylo = clampi(a.yofs[yA], 0, a.h0 - 1) - r;
     const int yhi = clampi(a.yofs[yB] + 1, 0, a.h0 - 1) + r;
     const int nrows = yhi - ylo + 1;
@@ -274,7 +275,7 @@ __global__ __launch_bounds__(256) void tw_pyr_level(PyrArgs a)
     // ---- column filter at the sampled rows + resize combine ----
     const int tx = tid & (PYR_TW - 1), ty = tid / PYR_TW;
     const int ox = x0 + tx, oy = y0 + ty;
-    if (ox >= a.w || oy >= a.h) return;
+    if (ox >= a.w || oy >= a.h || ty >= a.th) return;
     const int sy = a.yofs[oy];
     const int s0 = clampi(sy, 0, a.h0 - 1) - ylo, s1 = clampi(sy + 1, 0, a.h0 - 1) - ylo;
 
