@@ -620,7 +620,10 @@ def test_single_pair_schedule_of_twin_launches(twflow, oracle):
     import synth
     cases = [((1080, 1920), {}, True), ((720, 1280), {}, False), ((480, 640), {}, True), ((240, 424), {}, True),
              ((483, 645), {}, False), ((480, 640), {"pyrIterations": 1}, True), ((480, 640), {"pyrIterations": 2}, False),
-             ((480, 640), {"pyrIterations": 5}, False), ((480, 640), {"pyrLevels": 2}, False), ((544, 960), {"pyrLevels": 5}, False)]
+             ((480, 640), {"pyrIterations": 5}, False), ((480, 640), {"pyrLevels": 2}, False), ((544, 960), {"pyrLevels": 5}, False),
+             # round 6: level 1's window launches carry level 0's expansion (tw_twin_s4_poly) where level 1 takes the 96 x 8 tiles
+             ((720, 1280), {"pyrIterations": 2}, True), ((720, 1280), {"pyrIterations": 1}, False),
+             ((720, 1280), {"pyrIterations": 5}, False), ((656, 1160), {}, True)]
     for (h, w), kw, with_oracle in cases:
         a, b = synth.make_pair(7, h, w)
         with twflow.Engine(0, twflow.default_params(**kw), slots=1) as e:
@@ -629,9 +632,26 @@ def test_single_pair_schedule_of_twin_launches(twflow, oracle):
             v2 = e.diff(b, a, 10, 0.5)["vector"]   # the same buffers again, the other way round
             cnt = e.launch_counts()
             assert cnt.flow_iter() == 0, cnt  # a single pair keeps the tile kernels
-            if not kw and (h, w) in ((1080, 1920), (480, 640)):
+            if not kw and (h, w) == (480, 640):
                 # the twin schedule is what ran: every polynomial expansion and the level 0 / 1 images rode in a chain launch
-                assert cnt["tw_twin"] >= 3 * 5 and cnt["tw_polyexp"] == 0 and cnt["tw_pyr_k3f"] == 0, cnt
+                assert cnt["tw_twin"] == 3 * 5 and cnt["tw_polyexp"] == 0 and cnt["tw_pyr_k3f"] == 0, cnt
+            if (h, w) in ((1080, 1920), (720, 1280), (656, 1160)):
+                # ... and level 1's `it` window launches were twins too: only level 0's are plain tw_blur_solve4 launches
+                it = kw.get("pyrIterations", 3)
+                assert cnt["tw_twin"] == 3 * (2 + 2 * it) and cnt["tw_blur_solve4"] == 3 * it, (h, w, kw, cnt)
+                assert cnt["tw_polyexp"] == 0 and cnt["tw_pyr_k3f"] == 0, cnt
+        if (h, w) == (1080, 1920) or kw.get("pyrIterations") == 2:
+            os.environ["TW_LAT_PLAN"] = "0"  # round 5's plan (everything on level 3's launches): still there, same values
+            try:
+                with twflow.Engine(0, twflow.default_params(**kw), slots=1) as e:
+                    px, py, _ = e.calculate_internal(a, b)
+                    assert e.diff(a, b, 10, 0.5)["vector"] == v
+                    c0 = e.launch_counts()
+                    assert c0["tw_twin"] == 2 * 5, (kw, c0)  # (2 iterations: level 2's update carries the fourth job)
+            finally:
+                del os.environ["TW_LAT_PLAN"]
+            assert_same(gx, px, "flowx, plan 0 %dx%d %r" % (w, h, kw))
+            assert_same(gy, py, "flowy, plan 0 %dx%d %r" % (w, h, kw))
         os.environ["TW_LAT_FUSED"] = "0"
         try:
             with twflow.Engine(0, twflow.default_params(**kw), slots=1) as e:

@@ -886,6 +886,8 @@ struct ProfScope {
 struct SideJob {
     int kind = 0;        // 1: polynomial-expansion band (tw_polyexp_pk<7, 8, 0>), 2: tw_pyr_k3f
     int need_level = 0;  // the finest level whose flow chain reads what the job writes
+    int carry_level = -1;       // >= 0: only a chain launch of this level carries the job
+    bool windows_only = false;  // ... and only its window launches, not its FarnebackUpdateMatrices launch
     PolyArgs pa;
     PyrK3fArgs ka;
     VGrid g;             // the job's workgroups
@@ -1374,7 +1376,14 @@ void launch_blur(tw_engine* e, hipStream_t st, int w, int h, int ld, long long p
             const dim3 grid((w + a.xsh + tw - 1) / tw, (h + th - 1) / th, npairs);
             if (small == 1) {
                 set_grid_out();
-                TW_LAUNCH(e, TW_DF_BLUR_SOLVE4, (tw_blur_solve4<15, 128, 16, 8, true>), grid, dim3(128), 0, st, a);
+                if (side && side_used && side->kind == 1) {
+                    // (round 6) two-wave workgroups that leave most of the chip idle: a band of a finer level's expansion rides along
+                    const TwinGrid t = make_twin(grid, *side);
+                    TW_LAUNCH(e, TW_DF_TWIN, tw_twin_s4_poly, dim3(t.nA8 + side->n()), dim3(256), 0, st, a, side->pa, t);
+                    *side_used = true;
+                } else {
+                    TW_LAUNCH(e, TW_DF_BLUR_SOLVE4, (tw_blur_solve4<15, 128, 16, 8, true>), grid, dim3(128), 0, st, a);
+                }
             }
 #ifdef TW_VARIANTS
             else if (small == 2) TW_LAUNCH(e, TW_DF_BLUR_SOLVE4, (tw_blur_solve4<15, 128, 16, 4, true>), grid, dim3(128), 0, st, a);
@@ -1627,11 +1636,13 @@ tw_status flush_ctx(tw_engine* e, Ctx& c)
         return TW_OK;
     };
     // the side jobs of the twin schedule, in the order the chain needs their results
-    auto side_poly = [&](int k, int z0, int nz, int y0, int ny) {
+    auto side_poly = [&](int k, int z0, int nz, int y0, int ny, int carry_level = -1, bool windows_only = false) {
         const LevelPlan& L = pl->lv[k];
         SideJob j;
         j.kind = 1;
         j.need_level = k;
+        j.carry_level = carry_level;
+        j.windows_only = windows_only;
         j.pa.src = e->lat_I + lat_off[k];
         j.pa.dst = e->lat_R + 5 * lat_off[k];
         j.pa.w = L.w;
@@ -1651,6 +1662,12 @@ tw_status flush_ctx(tw_engine* e, Ctx& c)
     auto side_peek = [&]() -> const SideJob* {
         if (side_next >= sideq.size()) return nullptr;
         return side_alone == 2 ? &empty_side : side_alone ? nullptr : &sideq[side_next];
+    };
+    // may a launch of level k's chain (its update launch / one of its window launches) carry the next job?
+    auto side_ok = [&](int k, bool window) -> bool {
+        if (side_next >= sideq.size()) return false;
+        const SideJob& j = sideq[side_next];
+        return (j.carry_level < 0 || j.carry_level == k) && (window || !j.windows_only);
     };
     auto side_done = [&](bool used) {
         if (side_next >= sideq.size()) return;
@@ -1700,6 +1717,23 @@ tw_status flush_ctx(tw_engine* e, Ctx& c)
         static const int bands_env = getenv("TW_LAT_BANDS") ? atoi(getenv("TW_LAT_BANDS")) : 0;
         (void)carriers;
         side_poly(2, 0, 2, 0, gy2);
+        // TW_LAT_PLAN=0: round 5's plan — everything on level 3's launches (level 1's expansion, then level 0's image by image).
+        // 1 (default, round 6): level 1's expansion in `it` bands on level 3's window launches, level 0's in `it` bands (of both
+        // images) on LEVEL 1's window launches (tw_twin_s4_poly: 680 two-wave workgroups leave the chip three quarters idle);
+        // levels 2's launches and level 1's update carry nothing (they fill the chip: a carried job costs 0.7 of itself there).
+        const int plan_env = getenv("TW_LAT_PLAN") ? atoi(getenv("TW_LAT_PLAN")) : 1;  // (read per batch: the tests switch it)
+        const bool l1_twin = pl->lv[1].w > 480 && (long long)((pl->lv[1].w + 95) / 96) * ((pl->lv[1].h + 7) / 8) * 2 >= e->pp_waves &&
+                             (long long)((pl->lv[1].w + 223) / 224) * ((pl->lv[1].h + 7) / 8) < 1024 && e->blur_small < 0 &&
+                             e->blur_small_lv[1] < 0;  // level 1 takes the 96 x 8 tiles (launch_blur)
+        if (plan_env >= 1 && l1_twin && bands_env == 0) {
+            auto bands = [&](int k, int gy, int nb, int carry) {  // level k's expansion (both images) as nb bands of tile rows
+                const int rows = (gy + nb - 1) / nb;
+                for (int y0 = 0; y0 < gy; y0 += rows) side_poly(k, 0, 2, y0, std::min(rows, gy - y0), carry, true);
+            };
+            bands(1, gy1, it, 3);
+            bands(0, gy0, it, 1);  // (unequal bands, two of five bands on level 3's launches: all within the noise of this,
+                                   //  profiles/r06_single_pair.md)
+        } else {
         if (bands_env >= 2) {
             side_poly(1, 0, 1, 0, gy1);
             side_poly(1, 1, 1, 0, gy1);
@@ -1710,6 +1744,7 @@ tw_status flush_ctx(tw_engine* e, Ctx& c)
         const int rows = (gy0 + nb - 1) / nb;
         for (int z = 0; z < 2; z++)
             for (int y0 = 0; y0 < gy0; y0 += rows) side_poly(0, z, 1, y0, std::min(rows, gy0 - y0));
+        }
     } else if (lat) {
         if ((r = lat_images(pl->levels))) return r;
         if (pl->levels >= 1 && (r = lat_images(pl->levels - 1))) return r;
@@ -1818,7 +1853,7 @@ tw_status flush_ctx(tw_engine* e, Ctx& c)
                     iterated = true;
                 }
                 if (!iterated) {
-                    if (lat2 && k >= 1) {
+                    if (lat2 && k >= 1 && side_ok(k, false)) {
                         bool used = false;
                         launch_update(e, ls, pl, k, R, flow_cur, flow_prev, M0, nc, side_peek(), &used);
                         side_done(used);
@@ -1843,7 +1878,7 @@ tw_status flush_ctx(tw_engine* e, Ctx& c)
                         TW_LAUNCH(e, TW_DF_BLUR_GRID, (tw_blur_grid<15, 10, 2>), dim3((g.gw + 21) / 22, (g.gh + 1) / 2, nc), dim3(256), 0, ls, g);
                         break;
                     }
-                    if (lat2 && k >= 2) {
+                    if (lat2 && k >= 1 && side_ok(k, true)) {
                         bool used = false;
                         launch_blur(e, ls, L.w, L.h, L.ld, L.ps, (i & 1) ? M1 : M0, (i & 1) ? M0 : M1, flow_cur, R, i < it - 1, k, nc,
                                     nullptr, side_peek(), &used);

@@ -1288,13 +1288,20 @@ __device__ __forceinline__ f32x2 pe_mad(f32x2 a, float b, f32x2 c)
     if constexpr (FUSE) return __builtin_elementwise_fma(a, f32x2{b, b}, c);
     else return a * b + c;
 }
-template <int N, int TH, int F32ACC = 0>
-__device__ __forceinline__ void tw_polyexp_pk_body(const PolyArgs& a, const VGrid& vg, const unsigned vb)
+template <int N, int TH, int F32ACC = 0, bool EXT_LDS = false>
+__device__ __forceinline__ void tw_polyexp_pk_body(const PolyArgs& a, const VGrid& vg, const unsigned vb, void* ext_lds = nullptr)
 {
     constexpr bool FUSE = F32ACC == 2;
     constexpr int RP = TH / 2, NW = TH + 2 * N, NPA = NW / 2, NPB = NW / 2 - 1;
     static_assert(NW % 2 == 0 && PE_TW % 2 == 0 && N <= PE_HALO - 1, "tile shape");
-    __shared__ __attribute__((aligned(16))) f32x2 sm[3][RP][PE_COLS];
+    // EXT_LDS: the 3 x RP x PE_COLS float2 tile lives in the caller's LDS block (a twin launch overlays it with its other body's)
+    f32x2 (*sm)[RP][PE_COLS];
+    if constexpr (EXT_LDS) {
+        sm = (f32x2 (*)[RP][PE_COLS])ext_lds;
+    } else {
+        __shared__ __attribute__((aligned(16))) f32x2 sm_own[3][RP][PE_COLS];
+        sm = sm_own;
+    }
     const int tid = threadIdx.x;
     int bx, by, bz;
     xcd_remap_v(vg, vb, bx, by, bz);
@@ -1846,15 +1853,16 @@ struct BlurArgs {
 //   S : lane-consecutive pixels: solve in double, store the flow, refresh M (R0 fetched before H, two R1
 //       gathers in flight per lane)
 // -----------------------------------------------------------------------------------------------------
+// (the body over a virtual grid and a caller-owned LDS tile, so that a twin launch can run it beside another body and overlay the two
+//  bodies' LDS: tw_twin_s4_poly below; the plain kernel hands it the hardware grid and its own tile — same values, same code)
 template <int MH, int COLS, int HALO, int TH, bool FUSED, int VILP = 2, int HILP = 2, int SUNROLL = 2, bool QPRE = true, bool VPRE = true>
-__global__ __launch_bounds__(COLS) __attribute__((amdgpu_waves_per_eu(4, 8))) void tw_blur_solve4(BlurArgs a)
+__device__ __forceinline__ void tw_blur_solve4_body(const BlurArgs& a, const VGrid& vg, const unsigned vb, float (*sm)[TH][COLS])
 {
     constexpr int TW = COLS - 2 * HALO;
     constexpr int NW = TH + 2 * MH;
-    __shared__ __attribute__((aligned(16))) float sm[5][TH][COLS];
     const int tid = threadIdx.x;
     int bx, by, z;
-    xcd_remap(bx, by, z);
+    xcd_remap_v(vg, vb, bx, by, z);
     // the tile grid starts XSH pixels left of the image so that a wave's 256-byte row segment (which begins HALO
     // pixels left of its tile) is 128-byte aligned: two cache lines per load instead of three
     const int x0 = bx * TW - a.xsh, y0 = by * TH;
@@ -2079,6 +2087,12 @@ __global__ __launch_bounds__(COLS) __attribute__((amdgpu_waves_per_eu(4, 8))) vo
             }
         }
     }
+}
+template <int MH, int COLS, int HALO, int TH, bool FUSED, int VILP = 2, int HILP = 2, int SUNROLL = 2, bool QPRE = true, bool VPRE = true>
+__global__ __launch_bounds__(COLS) __attribute__((amdgpu_waves_per_eu(4, 8))) void tw_blur_solve4(BlurArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float sm[5][TH][COLS];
+    tw_blur_solve4_body<MH, COLS, HALO, TH, FUSED, VILP, HILP, SUNROLL, QPRE, VPRE>(a, hw_grid(), hw_block(), sm);
 }
 
 // -----------------------------------------------------------------------------------------------------
@@ -3419,6 +3433,20 @@ __global__ __launch_bounds__(320) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
     } else {
         if (threadIdx.x >= 256) return;
         tw_polyexp_pk_body<7, 8, 0>(pa, t.b, blockIdx.x - t.nA8);
+    }
+}
+// chain: the 96 x 8-tile window kernel of a level too small to fill the chip (128 threads; BASELINE config 2's level 1) | side: a band
+// of the polynomial expansion (256 threads).  The two bodies' LDS tiles (20 KB / 24 KB) share one block: a workgroup runs one body.
+// (round 6: level 1's window launches are 680 two-wave workgroups, 1.3 waves per SIMD — the chip has room beside them)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) void tw_twin_s4_poly(BlurArgs ba, PolyArgs pa, TwinGrid t)
+{
+    constexpr size_t LDS_A = sizeof(float) * 5 * BS_TH * 128, LDS_B = sizeof(f32x2) * 3 * (PE_TH / 2) * PE_COLS;
+    __shared__ __attribute__((aligned(16))) char lds[LDS_A > LDS_B ? LDS_A : LDS_B];
+    if (blockIdx.x < t.nA8) {
+        if (blockIdx.x >= t.nA || threadIdx.x >= 128) return;
+        tw_blur_solve4_body<15, 128, 16, BS_TH, true>(ba, t.a, blockIdx.x, (float (*)[BS_TH][128])lds);
+    } else {
+        tw_polyexp_pk_body<7, PE_TH, 0, true>(pa, t.b, blockIdx.x - t.nA8, lds);
     }
 }
 // chain: the coarsest level's polynomial expansion | side: levels 0 and 1 of the images (tw_pyr_k3f, 256 threads, no remap)
