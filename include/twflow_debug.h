@@ -54,10 +54,11 @@ enum tw_debug_family {
     TW_DF_BLUR_VARIANT,    /* variants library only: tw_blur_solve4q / 4p / 6 */
     TW_DF_BLUR_GRID,       /* tw_blur_grid: scan-fused final iteration */
     TW_DF_BOX,             /* tw_box_vscan / tw_box_hscan_solve */
-    TW_DF_TWIN,            /* tw_twin_*: two bodies in one launch (single-pair schedule) */
+    TW_DF_TWIN,            /* tw_twin_*: two bodies in one launch (single-pair schedule; tw_twin_s4_poly since round 6) */
     TW_DF_SPAN_GATHER,
     TW_DF_SPAN_SCAN,
     TW_DF_PNG_UNFILTER,
+    TW_DF_SPAN_SCAN_SEG,   /* tw_span_scan_seg: a single pair's ordered scan in 16 independent segments (round 6) */
     TW_DF_COUNT
 };
 

@@ -670,6 +670,36 @@ def test_single_pair_schedule_of_twin_launches(twflow, oracle):
             assert v == oracle.span_scan(wx, wy, 10, 0.5)
 
 
+def test_single_pair_scan_in_segments(twflow, oracle):
+    """Round 6: a single pair's ordered span scan runs as 16 workgroups that each count the hits before their own segment
+    (tw_span_scan_seg) — same records in the same order and the same count as the one-workgroup kernel (TW_SCAN_SEG=0) and
+    the oracle, from no hit at all to every grid point a hit, for grids of 2 participants to 130 000 points; grids too large
+    or too small for it keep the one-workgroup kernel."""
+    import os
+    import synth
+    a, b = synth.make_pair(3, 1080, 1920)
+    small = synth.make_pair(5, 240, 424)
+    wx, wy = oracle.farneback(a, b, oracle.default_params())
+    with twflow.Engine(0, twflow.default_params(), slots=1) as e:
+        for span, thr in ((10, 0.0), (10, 0.5), (10, 1e9), (4, 0.0), (4, 2.0), (3, 0.7), (7, 0.0), (1, 5.0), (64, 0.0)):
+            e.launch_counts(reset=True)
+            v = e.diff(a, b, span, thr)["vector"]
+            cnt = e.launch_counts(reset=True)
+            seg = span in (10, 4, 3, 7)  # 2 048 < grid points, 16 segments of at most 32 768
+            assert (cnt["tw_span_scan_seg"], cnt["tw_span_scan"]) == ((1, 0) if seg else (0, 1)), (span, cnt)
+            assert v == oracle.span_scan(wx, wy, span, thr), (span, thr)
+            os.environ["TW_SCAN_SEG"] = "0"
+            try:
+                assert e.diff(a, b, span, thr)["vector"] == v, (span, thr)
+            finally:
+                del os.environ["TW_SCAN_SEG"]
+            cnt = e.launch_counts(reset=True)
+            assert (cnt["tw_span_scan_seg"], cnt["tw_span_scan"]) == (0, 1), (span, cnt)
+        sx, sy = oracle.farneback(small[0], small[1], oracle.default_params())
+        for span, thr in ((10, 0.0), (2, 0.0), (2, 0.3)):
+            assert e.diff(small[0], small[1], span, thr)["vector"] == oracle.span_scan(sx, sy, span, thr), (span, thr)
+
+
 def test_scan_fused_final_on_top_of_m_free_iterations(twflow, oracle):
     """Round 5: with TW_OPT_SCAN_FUSED_FINAL the level-0 iterations but the last run tw_flow_iter, the last flow's M comes
     from tw_update_matrices<false> and tw_blur_grid evaluates the span-grid points from it — same vectors as the oracle

@@ -388,7 +388,8 @@ struct tw_engine {
     int mfree = 1;         // TW_MFREE=0: every level runs update + blur launches again (A/B; tw_flow_iter, no M in HBM, is the
                            // default); 2: tw_flow_iter also for launches of a few workgroups (tests, tools/fuzz_parity.py)
     int cu_count = 256;
-    int pyr23_threads = 512;  // TW_PYR23_THREADS=256: tw_pyr_23 with four instead of eight waves per workgroup (A/B)
+    int pyr23_threads = 0;    // TW_PYR23_THREADS=256 / 512 / 1024: waves per tw_pyr_23 workgroup (A/B); 0 = 512, and 1024 for a
+                              // single pair (432 workgroups: sixteen waves cover the staging latency, -0.5 us of 10.6)
     int blur_cm = 0;       // TW_BLUR_CM=1: tw_blur_solve4y (51-tap window) walks an XCD's tiles column-major (A/B)
     int pyr_fused = 1;     // TW_PYR_FUSED=0: levels 2 and 3 as two tw_pyr_taps launches again (A/B; tw_pyr_23 is the default)
     int pyr_generic = 0;   // TW_PYR_GENERIC=1: always the generic pyramid kernel, 2: tw_pyr_level_lds for every level (A/B)
@@ -1039,7 +1040,9 @@ void launch_pyr23(tw_engine* e, hipStream_t st, const Plan* pl, const uint8_t* c
     memcpy(a.k9, pl->k9, sizeof(a.k9));
     ProfScope ps(e, st, TW_K_PYR, 3);
     const dim3 grid((L3.w + P23_T3W - 1) / P23_T3W, (L3.h + P23_T3H - 1) / P23_T3H, nimg);
-    if (e->pyr23_threads == 256) TW_LAUNCH(e, TW_DF_PYR_23, tw_pyr_23<256>, grid, dim3(256), 0, st, a);
+    const int nt = e->pyr23_threads ? e->pyr23_threads : nimg <= 2 ? 1024 : 512;
+    if (nt == 256) TW_LAUNCH(e, TW_DF_PYR_23, tw_pyr_23<256>, grid, dim3(256), 0, st, a);
+    else if (nt == 1024) TW_LAUNCH(e, TW_DF_PYR_23, tw_pyr_23<1024>, grid, dim3(1024), 0, st, a);
     else TW_LAUNCH(e, TW_DF_PYR_23, tw_pyr_23<512>, grid, dim3(512), 0, st, a);
 }
 
@@ -1995,7 +1998,16 @@ tw_status flush_ctx(tw_engine* e, Ctx& c)
             TW_LAUNCH(e, TW_DF_SPAN_SCAN, tw_span_scan<true>, dim3(n), dim3(1024), 0, st, a);
         } else
 #endif
-        TW_LAUNCH(e, TW_DF_SPAN_SCAN, tw_span_scan<false>, dim3(n), dim3(1024), 0, st, a);
+        {
+            // a single pair: 16 segments, each workgroup counting the hits before its own (tw_span_scan_seg: -5 us of one CU's VALU time)
+            const long long G = (long long)a.gw * a.gh;
+            const int S = (int)(((G + 15) / 16 + 1023) / 1024 * 1024);
+            const bool scan_seg = !getenv("TW_SCAN_SEG") || atoi(getenv("TW_SCAN_SEG")) != 0;  // (read per batch: a test compares the two kernels)
+            if (n == 1 && lat && scan_seg && G > 2048 && S <= SCAN_IT * 1024)
+                TW_LAUNCH(e, TW_DF_SPAN_SCAN_SEG, tw_span_scan_seg, dim3((unsigned)((G + S - 1) / S)), dim3(1024), 0, st, a, S);
+            else
+                TW_LAUNCH(e, TW_DF_SPAN_SCAN, tw_span_scan<false>, dim3(n), dim3(1024), 0, st, a);
+        }
     }
     TW_HIP(e, hipEventRecord(c.ev_stop, st));
     if (c.span > 0) {
@@ -2388,7 +2400,7 @@ tw_status tw_engine_create(int device, const tw_params* params, int slots, tw_en
     if (const char* ev = getenv("TW_PYR_GENERIC")) e->pyr_generic = atoi(ev);
     if (const char* ev = getenv("TW_PYR_FUSED")) e->pyr_fused = atoi(ev) != 0;
     if (const char* ev = getenv("TW_BLUR_CM")) e->blur_cm = atoi(ev);
-    if (const char* ev = getenv("TW_PYR23_THREADS")) e->pyr23_threads = atoi(ev) == 256 ? 256 : 512;
+    if (const char* ev = getenv("TW_PYR23_THREADS")) e->pyr23_threads = atoi(ev) == 256 ? 256 : atoi(ev) == 1024 ? 1024 : atoi(ev) == 512 ? 512 : 0;
     if (const char* ev = getenv("TW_MFREE")) e->mfree = atoi(ev);
     if (const char* ev = getenv("TW_MFREE_MIN_PX")) e->mfree_min_px = atoll(ev);
     if (const char* ev = getenv("TW_MFREE_MIN_W")) e->mfree_min_w = std::max(31, atoi(ev));
@@ -3026,7 +3038,7 @@ extern "C" const char* tw_debug_family_name(int family)
         "tw_pyr_k3", "tw_pyr_k3f", "tw_pyr_23", "tw_pyr_taps", "tw_pyr_level", "tw_polyexp", "tw_update_matrices",
         "tw_flow_iter", "tw_flow_iter_ups", "tw_flow_iter_zero", "tw_blur_solve4", "tw_blur_solve4y", "tw_blur_solve8",
         "tw_blur_solve_pp", "tw_blur_solve_generic", "tw_blur_variant", "tw_blur_grid", "tw_box", "tw_twin",
-        "tw_span_gather", "tw_span_scan", "tw_png_unfilter"};
+        "tw_span_gather", "tw_span_scan", "tw_png_unfilter", "tw_span_scan_seg"};
     return (family >= 0 && family < TW_DF_COUNT) ? names[family] : nullptr;
 }
 

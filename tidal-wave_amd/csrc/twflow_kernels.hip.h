@@ -821,10 +821,12 @@ __global__ __launch_bounds__(NT) void tw_pyr_23(Pyr23Args a)
     }
     // level 2: 600 outputs; 256 threads: the third round goes to the threads that had no level-3 pixel; 512 threads: the
     // second round (88 outputs) likewise
-    constexpr int NRND = NT == 256 ? 3 : 2, LAST0 = NT == 256 ? 168 : 424;
+    // (1024 threads — the single-pair schedule: one round, by the 600 threads behind the 150 that had a level-3 pixel)
+    constexpr int NRND = NT == 256 ? 3 : NT == 512 ? 2 : 1, LAST0 = NT == 256 ? 168 : NT == 512 ? 424 : P23_T3W * P23_T3H;
     for (int i = 0; i < NRND; i++) {
         const int t = i < NRND - 1 ? tid + NT * i : tid - LAST0 + NT * (NRND - 1);
         if (i == NRND - 1 && tid < LAST0) break;
+        if (NT > 512 && t >= 4 * P23_T3W * P23_T3H) break;
         const int y = t / (2 * P23_T3W), x = t - y * (2 * P23_T3W);
         const int ox = bx * (2 * P23_T3W) + x, oy = by * (2 * P23_T3H) + y;
         const float* kc = a.k9 + 1 + 4;
@@ -4157,6 +4159,89 @@ __global__ __launch_bounds__(1024) void tw_span_scan(ScanArgs a)
         __syncthreads();
     }
     if (tid == 0) a.count[z] = base_out;
+}
+
+// tw_span_scan_seg (round 6, the single-pair schedule): the same ordered compaction by NSEG workgroups with no exchange between
+//   them.  One workgroup's 16 waves spend ~5 us of VALU issue on a 1080p pair's 20 736 points (tw_span_scan: 8 us of a 350 us pair);
+//   here workgroup g owns the points [g*S, (g+1)*S) and finds its output offset by COUNTING the hits before its segment itself
+//   (5 instructions per point, all loads in flight) — the last workgroup re-reads 15/16 of the grid from L2, nothing waits on
+//   anything.  Same compare (float len, double threshold), same row-major order of the records, same count.
+__global__ __launch_bounds__(1024) void tw_span_scan_seg(ScanArgs a, int S)
+{
+    __shared__ int wsum[SCAN_IT * 16];
+    __shared__ int wtot[16];
+    __shared__ int wpre[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int G = a.gw * a.gh;
+    const int lo = (int)blockIdx.x * S, hi = min(G, lo + S);
+    const float2* __restrict__ gdense = a.g;
+    // hits before the segment
+    int c = 0;
+    for (int i0 = 0; i0 < lo; i0 += 8 * 1024) {
+        float2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int idx = i0 + u * 1024 + tid;
+            v[u] = float2{0.f, 0.f};
+            if (idx < lo) v[u] = gdense[idx];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int idx = i0 + u * 1024 + tid;
+            const float len = (v[u].x * v[u].x) + (v[u].y * v[u].y);
+            c += (idx < lo && (double)len > a.thr2) ? 1 : 0;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) c += __shfl_xor(c, off);
+    if (lane == 0) wpre[wave] = c;
+    // the segment itself: one round of tw_span_scan (S <= SCAN_IT * 1024)
+    const int nit = (hi - lo + 1023) / 1024;
+    unsigned mask = 0;
+    for (int i = 0; i < nit; i++) {
+        const int idx = lo + i * 1024 + tid;
+        float2 v = float2{0.f, 0.f};
+        if (idx < hi) v = gdense[idx];
+        const float len = (v.x * v.x) + (v.y * v.y);
+        const bool f = idx < hi && (double)len > a.thr2;
+        const unsigned long long b = __ballot(f);
+        if (lane == 0) wsum[i * 16 + wave] = __popcll(b);
+        mask |= f ? (1u << i) : 0u;
+    }
+    __syncthreads();
+    int base_out = 0;
+#pragma unroll
+    for (int w2 = 0; w2 < 16; w2++) base_out += wpre[w2];
+    const int ne = nit * 16;
+    const int mine = (tid < ne) ? wsum[tid] : 0;
+    int incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off);
+        if (lane >= off) incl += t;
+    }
+    if (lane == 63) wtot[wave] = incl;
+    __syncthreads();
+    for (int w2 = 0; w2 < wave; w2++) incl += wtot[w2];
+    if (tid < ne) wsum[tid] = incl - mine;
+    if (hi == G && tid == max(ne, 1) - 1) a.count[0] = base_out + (ne > 0 ? incl : 0);  // the workgroup of the last segment
+    __syncthreads();
+    for (int i = 0; i < nit; i++) {
+        const bool f = (mask >> i) & 1u;
+        const unsigned long long b = __ballot(f);
+        if (f) {
+            const int idx = lo + i * 1024 + tid;
+            const int gy = idx / a.gw, gx = idx - gy * a.gw;
+            const int pos = base_out + wsum[i * 16 + wave] + __popcll(b & ((1ull << lane) - 1ull));
+            const float2 vv = gdense[idx];
+            ScanRec rr;
+            rr.x = gx * a.span;
+            rr.y = gy * a.span;
+            rr.dx = vv.x;
+            rr.dy = vv.y;
+            a.rec[pos] = rr;
+        }
+    }
 }
 
 // =====================================================================================================
