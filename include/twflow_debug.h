@@ -59,6 +59,7 @@ enum tw_debug_family {
     TW_DF_SPAN_SCAN,
     TW_DF_PNG_UNFILTER,
     TW_DF_SPAN_SCAN_SEG,   /* tw_span_scan_seg: a single pair's ordered scan in 16 independent segments (round 6) */
+    TW_DF_BLUR_SOLVE4Q,    /* tw_blur_solve4q: solve + refresh by the horizontal item's owner — a single pair's level-0 launches (round 6) */
     TW_DF_COUNT
 };
 

@@ -638,8 +638,25 @@ def test_single_pair_schedule_of_twin_launches(twflow, oracle):
             if (h, w) in ((1080, 1920), (720, 1280), (656, 1160)):
                 # ... and level 1's `it` window launches were twins too: only level 0's are plain tw_blur_solve4 launches
                 it = kw.get("pyrIterations", 3)
-                assert cnt["tw_twin"] == 3 * (2 + 2 * it) and cnt["tw_blur_solve4"] == 3 * it, (h, w, kw, cnt)
+                assert cnt["tw_twin"] == 3 * (2 + 2 * it), (h, w, kw, cnt)
                 assert cnt["tw_polyexp"] == 0 and cnt["tw_pyr_k3f"] == 0, cnt
+                # level 0: 224 x 8 tiles at 1080p — a single pair's take tw_blur_solve4q (solve + refresh by the horizontal item's
+                # owner, span-grid samples included: no tw_span_gather launch); the smaller sizes' 96 x 8 tiles stay tw_blur_solve4
+                quads = (h, w) == (1080, 1920)
+                assert (cnt["tw_blur_solve4"], cnt["tw_blur_solve4q"]) == ((0, 3 * it) if quads else (3 * it, 0)), (h, w, kw, cnt)
+                assert cnt["tw_span_gather"] == 0, cnt
+        if (h, w) == (1080, 1920):
+            os.environ["TW_LAT_QUADS"] = "0"  # level 0 through tw_blur_solve4, as in a batch: same values
+            try:
+                with twflow.Engine(0, twflow.default_params(**kw), slots=1) as e:
+                    qx, qy, _ = e.calculate_internal(a, b)
+                    assert e.diff(a, b, 10, 0.5)["vector"] == v
+                    c0 = e.launch_counts()
+                    assert (c0["tw_blur_solve4"], c0["tw_blur_solve4q"]) == (2 * 3, 0), c0
+            finally:
+                del os.environ["TW_LAT_QUADS"]
+            assert_same(gx, qx, "flowx, TW_LAT_QUADS=0")
+            assert_same(gy, qy, "flowy, TW_LAT_QUADS=0")
         if (h, w) == (1080, 1920) or kw.get("pyrIterations") == 2:
             os.environ["TW_LAT_PLAN"] = "0"  # round 5's plan (everything on level 3's launches): still there, same values
             try:
@@ -668,6 +685,26 @@ def test_single_pair_schedule_of_twin_launches(twflow, oracle):
             assert_same(gx, wx, "flowx vs oracle %dx%d %r" % (w, h, kw))
             assert_same(gy, wy, "flowy vs oracle %dx%d %r" % (w, h, kw))
             assert v == oracle.span_scan(wx, wy, 10, 0.5)
+
+
+def test_single_pair_level0_quads_on_ragged_sizes(twflow, oracle):
+    """Round 6: a single pair's 224 x 8-tile window launches run tw_blur_solve4q (the 16-byte-per-lane solve / refresh).  Sizes
+    that are not multiples of the tile or of four pixels (2001 x 1083: a one-pixel last group and a three-row last tile row;
+    1930 x 1100), with the span-grid samples stored by the last launch for spans that do and do not divide the size —
+    dense flow and vectors against the oracle."""
+    import synth
+    for (h, w), spans in (((1083, 2001), (10, 7)), ((1100, 1930), (4, 13))):
+        a, b = synth.make_pair(11, h, w)
+        wx, wy = oracle.farneback(a, b, oracle.default_params())
+        with twflow.Engine(0, twflow.default_params(), slots=1) as e:
+            gx, gy, _ = e.calculate_internal(a, b)
+            assert_same(gx, wx, "flowx %dx%d" % (w, h))
+            assert_same(gy, wy, "flowy %dx%d" % (w, h))
+            for span in spans:
+                for thr in (0.0, 0.8):
+                    assert e.diff(a, b, span, thr)["vector"] == oracle.span_scan(wx, wy, span, thr), (h, w, span, thr)
+            cnt = e.launch_counts()
+            assert cnt["tw_blur_solve4q"] == 5 * 3 and cnt["tw_span_gather"] == 0, cnt
 
 
 def test_single_pair_scan_in_segments(twflow, oracle):

@@ -2672,7 +2672,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     }
 }
 
-#ifdef TW_VARIANTS
 // -----------------------------------------------------------------------------------------------------
 // tw_blur_solve4q<MH,COLS,HALO,TH,FUSED> (round 4): tw_blur_solve4 with the solve + refresh done BY THE HORIZONTAL ITEM'S
 //   OWNER, four pixels of one row per lane.  The horizontal pass already leaves the window averages of a 4-pixel group in
@@ -2682,8 +2681,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 //   accesses + per-pixel dword taps move the same bytes 4-6 % faster, profiles/r04_refresh_shape.txt), two of the three
 //   workgroup barriers and 55 LDS accesses per lane and tile go away.  Same values, same order per value.
 //   MEASURED (profiles/r04_blur_quads.md): the last launch of a level -4 %, the refreshing launch +12 % (the 2x2 taps of
-//   lanes that sit 16 bytes apart touch four times the cache lines per instruction) — variants library only
-//   (TW_BLUR_VARIANT=9).
+//   lanes that sit 16 bytes apart touch four times the cache lines per instruction) — in a BATCH, where the launch is
+//   throughput-bound; the variants library keeps that A/B (TW_BLUR_VARIANT=9).
+//   Round 6: a SINGLE pair's level-0 launches are bound by the workgroup's serial V -> H -> S chain (1 215 workgroups on 1 024
+//   slots: one round and a tail), and there the two barriers and the LDS round trip this kernel leaves out are worth more than
+//   the taps' extra cache lines: 51.8 / 47.9 / 35.6 -> 48.6 / 44.5 / 33.3 us for the three launches of a 1080p pair
+//   (profiles/r06_single_pair.md) — the single-pair schedule's level-0 kernel since then, span-grid samples included (BlurArgs::grid).
 // -----------------------------------------------------------------------------------------------------
 template <int MH, int COLS, int HALO, int TH, bool FUSED, int VILP = 2, int HILP = 2>
 __global__ __launch_bounds__(COLS) __attribute__((amdgpu_waves_per_eu(4, 8))) void tw_blur_solve4q(BlurArgs a)
@@ -2820,6 +2823,19 @@ __global__ __launch_bounds__(COLS) __attribute__((amdgpu_waves_per_eu(4, 8))) vo
                         flow[(long long)yc * a.ld + x + j + a.fps] = fy4[j];
                     }
             }
+            if (a.gspan > 0 && y < a.h) {  // (wave-uniform) the span-grid samples of the stored flow, as tw_blur_solve4 writes them
+                const unsigned qy = __umulhi((unsigned)y, a.gmagic);
+                if (qy * (unsigned)a.gspan == (unsigned)y) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const int xj = x + j;
+                        if (xj >= 0 && xj < a.w) {
+                            const unsigned qx = __umulhi((unsigned)xj, a.gmagic);
+                            if (qx * (unsigned)a.gspan == (unsigned)xj) a.grid[((long long)z * a.gh + qy) * a.gw + qx] = float2{fx4[j], fy4[j]};
+                        }
+                    }
+                }
+            }
         }
         if (FUSED) {
             if (a.update) {  // wave-uniform
@@ -2848,7 +2864,6 @@ __global__ __launch_bounds__(COLS) __attribute__((amdgpu_waves_per_eu(4, 8))) vo
         }
     }
 }
-#endif  // TW_VARIANTS (tw_blur_solve4q)
 
 #ifdef TW_VARIANTS  // round-3 trial (TW_BLUR_PIPE), measured 55 % slower: VARIANTS=1 builds only (profiles/r03_blur_pipeline_negative.md)
 // -----------------------------------------------------------------------------------------------------
