@@ -13,11 +13,17 @@ import twflow as T  # noqa: E402
 
 
 def main():
+    if os.environ.get("TW_LAT_TORCH") == "1":  # A/B: the same loop in a process that also holds PyTorch's HIP context (bench.py's)
+        import torch
+        torch.cuda.init()
+        torch.cuda.set_device(0)
+        _t = torch.zeros(1 << 20, device="cuda")
+        torch.cuda.synchronize()
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
     sizes = [(1920, 1080), (640, 480), (180, 117)]
     if len(sys.argv) > 2:
         sizes = sizes[:int(sys.argv[2])]
-    with T.Engine(0, T.default_params(), slots=1) as e:
+    with T.Engine(0, T.default_params(), slots=int(os.environ.get("TW_LAT_SLOTS", "1"))) as e:
         for w, h in sizes:
             a, b = synth.make_pair(0, h, w)
             da, db = e.upload(a), e.upload(b)
