@@ -749,12 +749,14 @@ def main():
 
     # single-pair latency (configs[1]) and a result check before timing
     res0 = eng.diff(host_pairs[0][0], host_pairs[0][1], SPAN, THRESHOLD)
-    # (median of 21 after 3 unrecorded calls, as tools/latency.py does: the first calls after the host-side set-up run on a
-    #  card that has been idle for seconds — the 7-sample median of rounds 2-5 sat ~6 us above the tool's figure)
+    # (median of 300 after 10 unrecorded calls = 0.12 s: the first calls after the host-side set-up run on a card that has been
+    #  idle for seconds — the 7-sample median of rounds 2-5 sat ~6 us above tools/latency.py's 40-sample figure, which itself
+    #  sits ~10 us above the median of 20 000 calls back to back, gpurun_out/r8m)
+    LAT_WARM, LAT_N = 10, 300
     lat = []
-    for i in range(24):
+    for i in range(LAT_WARM + LAT_N):
         r = eng.wait(eng.submit_dev(dev_pairs[0][0], dev_pairs[0][1], W, H, W, SPAN, THRESHOLD))
-        if i >= 3:
+        if i >= LAT_WARM:
             lat.append(r["time"])
     assert r["vector"] == res0["vector"]
 
@@ -916,7 +918,10 @@ def main():
                        "numa_node_rank0": numa_node, "backend": backend if world > 1 else None,
                        "rehearsal": None if ndev >= world else "%d ranks time-share %d device(s): a rehearsal of the "
                                                               "N-device shape, not a scaling point" % (world, ndev),
-                       "single_pair_latency_ms": round(float(np.median(lat)) * 1e3, 4)},
+                       "single_pair_latency_ms": round(float(np.median(lat)) * 1e3, 4),
+                       "single_pair_latency_note": "device time of one 1080p pair per call (BASELINE configs[1]), median of %d "
+                                                   "calls back to back after %d unrecorded ones; min %.4f ms"
+                                                   % (LAT_N, LAT_WARM, float(np.min(lat)) * 1e3)},
             "measured_copy_GBps": copy_gbs,
             # rounds 1-3's `value` was --mode resident (pairs already in HBM); since round 4 it is --mode pinned
             # (uploads inside the timed region).  The resident-equivalent of this run is `resident_hbm.pairs_per_s`.

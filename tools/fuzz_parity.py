@@ -7,7 +7,9 @@ Round 2: seeds 2026, 7 and 99 = 6 400 cases, 0 mismatches.  FUZZ_FOCUS=win50: wi
 FUZZ_FOCUS=mfree (round 5): tw_flow_iter — winSize 30 / 31, Gaussian window, 320..1500-pixel-wide images of 20..560 rows, forced
 for single pairs (TW_MFREE=2, no single-pair stream split) so that every level of >= 320 columns runs it.
 FUZZ_FOCUS=twin (round 5): the single-pair schedule of twin launches — sizes that are multiples of 8 (256..1280 x 200..800),
-polyN 7, winSize 30 / 31, pyrScale 0.5, pyrLevels 3-5, 1-5 iterations, slots = 1."""
+polyN 7, winSize 30 / 31, pyrScale 0.5, pyrLevels 3-5, 1-5 iterations, slots = 1.
+FUZZ_FOCUS=big (round 6): single pairs of 1700..2300 x 900..1300 pixels (any remainder), whose level 0 takes the 224 x 8 tiles of
+tw_blur_solve4q — polyN 5 / 7, winSize 30 / 31, pyrScale 0.5 / 0.6, 1-4 levels, 1-3 iterations (a case takes ~3 s of oracle time)."""
 import sys, os, time
 if os.environ.get("FUZZ_FOCUS","")=="mfree":
     os.environ["TW_MFREE"]="2"; os.environ["TW_LATENCY_STREAMS"]="0"
@@ -23,9 +25,13 @@ while n < 3000 and time.time()-t0 < 240:
     if focus=="win50": h,w=int(rng.integers(1,520)),int(rng.integers(481,1500))
     if focus=="mfree": h,w=int(rng.integers(20,560)),int(rng.integers(320,1500))
     if focus=="twin": h,w=8*int(rng.integers(25,101)),8*int(rng.integers(32,161))
+    if focus=="big": h,w=int(rng.integers(900,1300)),int(rng.integers(1700,2300))  # round 6: a single pair's 224 x 8-tile level 0 (tw_blur_solve4q)
     kw=dict(polyN=int(rng.integers(1,8)), winSize=int(rng.choice([50,51])) if focus=="win50" else int(rng.choice([30,31])) if focus=="mfree" else int(rng.integers(2,66)), pyrLevels=int(rng.integers(0,7)),
             pyrIterations=int(rng.integers(0,6)), pyrScale=float(rng.choice([0.3,0.45,0.5,0.55,0.6,0.7,0.75,0.8,0.9])),
             flags=int(rng.choice([256,260])) if focus=="mfree" else int(rng.choice([0,256,4,260])), polySigma=float(rng.choice([0.0,0.8,1.1,1.5,2.2])))
+    if focus=="big":
+        kw=dict(polyN=int(rng.choice([5,7])), winSize=int(rng.choice([30,31])), pyrLevels=int(rng.integers(1,5)), pyrIterations=int(rng.integers(1,4)),
+                pyrScale=float(rng.choice([0.5,0.6])), flags=int(rng.choice([256,260])), polySigma=float(rng.choice([1.1,1.5])))
     if focus=="twin":
         kw=dict(polyN=7, winSize=int(rng.choice([30,31])), pyrLevels=int(rng.integers(3,6)), pyrIterations=int(rng.integers(1,6)),
                 pyrScale=0.5, flags=int(rng.choice([256,260])), polySigma=float(rng.choice([1.1,1.5])))
@@ -37,7 +43,7 @@ while n < 3000 and time.time()-t0 < 240:
     if kind==2 and h>8 and w>8: b[h//3:h//2,w//4:w//2]=0
     span=int(rng.integers(1,15)); thr=float(rng.choice([0.0,0.5,2.0,5.0]))
     try:
-        with T.Engine(0,T.default_params(**kw),slots=1 if focus=="twin" else 2) as e:
+        with T.Engine(0,T.default_params(**kw),slots=1 if focus in ("twin","big") else 2) as e:
             gx,gy,_=e.calculate_internal(a,b)
             v=e.diff(a,b,span,thr)["vector"]
     except T.TwError as ex:
