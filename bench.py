@@ -905,7 +905,9 @@ def main():
             "data": "synthetic",
             "config": {"workload": ("pinned: %d x 1920x1080 u8 gray pairs per GPU per step in page-locked HOST memory (a "
                                     "ring of %d distinct buffers), uploaded on the copy stream in %d-pair engine batches "
-                                    "INSIDE the timed region under the previous batch's kernels, hit records back "
+                                    "INSIDE the timed region under the previous batch's kernels (the first batch behind the "
+                                    "barrier finds the compute stream idle and goes out in pieces of 1/4 + 1/4 + 1/2 behind their "
+                                    "own uploads: the engine's cold-start ramp, TW_RAMP), hit records back "
                                     "(BASELINE configs[2]), %s" % (args.batch, args.batch, args.slots, PARAMS_TEXT))
                        if pinned_mode else
                        ("resident: batch of %d x 1920x1080 u8 gray pairs per GPU per step, resident in HBM, "

@@ -137,7 +137,11 @@ tw_status tw_submit_dev(tw_engine* e, const void* d_expect, const void* d_target
 /* Submitted pairs are gathered into a batch of up to `slots` pairs and executed together, level by level
  * (every kernel launch covers as many pairs as it takes to fill the GPU).  A batch starts executing when it
  * is full, when tw_flush is called, or when one of its tickets is waited for.  `seconds` of a pair is the
- * device time of its batch divided by the pairs in it (exact for a batch of one). */
+ * device time of its batch divided by the pairs in it (exact for a batch of one).
+ * Cold-start ramp (round 6; engines of >= 64 slots, host images): a batch that starts while nothing of an earlier
+ * batch is still executing goes out in up to three pieces — the first quarter of `slots`, the second quarter, the
+ * rest — each as soon as ITS uploads have arrived, instead of behind the batch's last upload; results, tickets and
+ * their order are the same (environment TW_RAMP=0 turns it off). */
 tw_status tw_flush(tw_engine* e);
 tw_status tw_wait(tw_engine* e, tw_ticket ticket, tw_vector* out, int cap, int* n, float* seconds);
 

@@ -277,6 +277,61 @@ def test_pipeline_with_m_free_iterations(twflow, oracle):
                 assert g == want[i % 2], "pyrIterations %d, pair %d" % (it, i)
 
 
+def test_cold_start_ramp(twflow, oracle):
+    """Round 6: a full batch of HOST pairs launched into an idle compute stream goes out in pieces — the first quarter, the
+    second quarter, the second half, each behind its own mark on the copy stream — instead of waiting for the batch's last
+    upload.  Same vectors as the oracle's for every pair; the launch counters prove the pieces (three polyexp launches per
+    level, the last over half of the batch), and that TW_RAMP=0, a batch of device-resident pairs and a batch smaller than a
+    quarter of the slots all take one launch per level."""
+    import os
+    import synth
+    h, w = 480, 640
+    distinct = [synth.make_pair(i, h, w) for i in range(4)]
+    want = _oracle_vectors(oracle, distinct, 10, 0.0)
+    assert "TW_RAMP" not in os.environ
+    with twflow.Engine(0, twflow.default_params(), slots=64) as e:
+        levels = e.num_levels(w, h)
+        for rnd in range(2):  # (the second batch finds the first one finished: idle again)
+            e.launch_counts(reset=True)
+            tk = [e.submit(*distinct[i % 4], 10, 0.0) for i in range(64)]
+            got = [e.wait(t)["vector"] for t in tk]
+            cnt = e.launch_counts()
+            assert cnt["tw_polyexp"] == 3 * (levels + 1) and cnt.last_z["tw_polyexp"] == 2 * 32, (cnt, cnt.last_z)
+            assert cnt["tw_span_scan"] == 1, cnt  # one ordered scan and one copy back for the whole batch
+            for i, g in enumerate(got):
+                assert len(want[i % 4]) > 1000 and g == want[i % 4], "round %d, pair %d" % (rnd, i)
+        # fewer pairs than the first mark: one piece
+        e.launch_counts(reset=True)
+        tk = [e.submit(*distinct[i % 4], 10, 0.0) for i in range(16)]
+        got = [e.wait(t)["vector"] for t in tk]
+        assert e.launch_counts()["tw_polyexp"] == levels + 1
+        assert all(g == want[i % 4] for i, g in enumerate(got))
+        # 40 pairs: [0, 16), [16, 32), [32, 40)
+        e.launch_counts(reset=True)
+        tk = [e.submit(*distinct[i % 4], 10, 0.0) for i in range(40)]
+        got = [e.wait(t)["vector"] for t in tk]
+        cnt = e.launch_counts()
+        assert cnt["tw_polyexp"] == 3 * (levels + 1) and cnt.last_z["tw_polyexp"] == 2 * 8, (cnt, cnt.last_z)
+        assert all(g == want[i % 4] for i, g in enumerate(got))
+        # device-resident pairs need no upload: nothing to ramp behind
+        dev = [(e.upload(a), e.upload(b)) for a, b in distinct]
+        e.launch_counts(reset=True)
+        tk = [e.submit_dev(dev[i % 4][0], dev[i % 4][1], w, h, w, 10, 0.0) for i in range(64)]
+        got = [e.wait(t)["vector"] for t in tk]
+        assert e.launch_counts()["tw_polyexp"] == levels + 1
+        assert all(g == want[i % 4] for i, g in enumerate(got))
+    os.environ["TW_RAMP"] = "0"
+    try:
+        with twflow.Engine(0, twflow.default_params(), slots=64) as e:
+            e.launch_counts(reset=True)
+            tk = [e.submit(*distinct[i % 4], 10, 0.0) for i in range(64)]
+            got = [e.wait(t)["vector"] for t in tk]
+            assert e.launch_counts()["tw_polyexp"] == levels + 1
+            assert all(g == want[i % 4] for i, g in enumerate(got))
+    finally:
+        del os.environ["TW_RAMP"]
+
+
 # ---------------------------------------------------------------------------------------------------
 # whole pipeline
 # ---------------------------------------------------------------------------------------------------

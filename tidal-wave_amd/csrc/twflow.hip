@@ -274,6 +274,12 @@ struct Ctx {
     uint8_t* d_img = nullptr;
     size_t d_img_cap = 0;
     hipEvent_t ev_h2d = nullptr;
+    // cold-start ramp (round 6): the copy stream is marked when a quarter and a half of a full batch's uploads have been
+    // queued (submit_common); a batch that is launched into an IDLE compute stream goes out in up to three pieces, each
+    // behind its own mark, instead of waiting for the last upload of the whole batch (flush_ctx)
+    hipEvent_t ev_seg[2] = {nullptr, nullptr};
+    int seg_at[2] = {0, 0};  // pairs queued when the mark was recorded
+    int nseg = 0;
     // tw_submit_png8: filtered PNG rows of the batch (2 slots of filt_slot bytes per job) and the job table of
     // tw_png_unfilter, which reconstructs them into d_img on the copy stream before ev_h2d
     uint8_t *d_filt = nullptr, *d_filt_raw = nullptr;  // d_filt = d_filt_raw + 256 (slack on both sides)
@@ -416,6 +422,7 @@ struct tw_engine {
     size_t lat_cap = 0;  // floats in lat_I (lat_R holds 5x)
     std::vector<hipEvent_t> lat_ev;
     int lat_s2_max = 1000;  // TW_LAT_S2_LEVELS: finest..this level's image-only work goes to the second stream
+    int ramp = 1;  // TW_RAMP=0: no cold-start ramp (A/B)
     int fi_maxseg = 4, fi_minsteps = 16;  // TW_FI_MAXSEG / TW_FI_MINSTEPS: most row segments per strip / fewest steps per segment (A/B)
     int fi_skip = 0;    // TW_FI_SKIP (variants library): timing experiments on tw_flow_iter (results are wrong)
     int fi_nt = 1024;   // TW_FI_NT=512 (variants library): tw_flow_iter as two 512-thread workgroups per CU on 64-output strips (A/B)
@@ -1540,6 +1547,7 @@ tw_status flush_ctx(tw_engine* e, Ctx& c)
         }
     }
     const int n = (int)c.jobs.size();
+    int ramp_b[4] = {0, 0, 0, 0}, ramp_n = 1;  // cold-start ramp: piece i = pairs [ramp_b[i], ramp_b[i + 1]); ramp_n - 1 pieces
     RoctxRange batch_range("tw_batch %dx%d pairs=%d", c.w, c.h, n);
     const size_t npx = staged_image_bytes(c.w, c.h);  // staged images are 256-byte aligned
     long long stride = c.jobs[0].stride;
@@ -1568,7 +1576,22 @@ tw_status flush_ctx(tw_engine* e, Ctx& c)
     if (c.any_host) {
         // the uploads were queued on the copy stream as the jobs came in (submit_common)
         TW_HIP(e, hipEventRecord(c.ev_h2d, e->copy_stream));
-        TW_HIP(e, hipStreamWaitEvent(st, c.ev_h2d, 0));
+        // cold-start ramp: nothing of an earlier batch is still running on the compute stream (the first batch after a
+        // pause, or a pipeline the host cannot keep filled) — the pairs whose uploads are already marked start now, the
+        // rest behind their own marks, instead of all of them behind the batch's last upload (531 MB for 128 pairs of
+        // 1080p: ~14 ms of an idle GPU).  A busy stream takes the whole batch in one launch per kernel and level, as before.
+        if (e->ramp && e->lanes == 1 && !c.any_png && c.nseg > 0 && c.seg_at[0] < n) {
+            bool idle = true;
+            for (Ctx& o : e->ctx)
+                if (&o != &c && o.launched && hipEventQuery(o.ev_done) == hipErrorNotReady) idle = false;
+            (void)hipGetLastError();  // (a "not ready" answer is not an error to report later)
+            if (idle) {
+                for (int i = 0; i < c.nseg; i++)
+                    if (c.seg_at[i] < n) ramp_b[ramp_n++] = c.seg_at[i];
+            }
+        }
+        ramp_b[ramp_n++] = n;
+        if (ramp_n == 2) TW_HIP(e, hipStreamWaitEvent(st, c.ev_h2d, 0));  // (no ramp: the whole batch behind its last upload)
         stride = c.w;
     }
     bool al4 = (stride % 4) == 0;
@@ -1757,9 +1780,14 @@ tw_status flush_ctx(tw_engine* e, Ctx& c)
         if ((r = lat_images(pl->levels))) return r;
         if (pl->levels >= 1 && (r = lat_images(pl->levels - 1))) return r;
     }
-    for (int lane = 0; lane < nlanes; lane++) {
+    const bool ramp = ramp_n > 2;  // (only with nlanes == 1 and never for a single pair: see where ramp_b is filled)
+    const int nparts = ramp ? ramp_n - 1 : nlanes;
+    for (int part = 0; part < nparts; part++) {
+        const int lane = ramp ? 0 : part;
         hipStream_t ls = lane == 0 ? st : e->stream2;
-        const int lo = (int)((long long)n * lane / nlanes), hi = (int)((long long)n * (lane + 1) / nlanes);
+        const int lo = ramp ? ramp_b[part] : (int)((long long)n * lane / nlanes);
+        const int hi = ramp ? ramp_b[part + 1] : (int)((long long)n * (lane + 1) / nlanes);
+        if (ramp) TW_HIP(e, hipStreamWaitEvent(st, part + 1 < nparts ? c.ev_seg[part] : c.ev_h2d, 0));
         float* I = e->I + ws_lane * lane;
         float* R = e->R + ws_lane * 5 * lane;
         float* M0 = e->M[0] + ws_lane / 2 * 5 * lane;
@@ -2161,6 +2189,7 @@ tw_status submit_common(tw_engine* e, const uint8_t* h_a, const uint8_t* h_b, co
         c->any_host = false;
         c->any_png = false;
         c->filt_slot = 0;
+        c->nseg = 0;
         c->first_ticket = e->next_ticket;
     }
     Job jb;
@@ -2279,6 +2308,14 @@ tw_status submit_common(tw_engine* e, const uint8_t* h_a, const uint8_t* h_b, co
     }
     c->jobs.push_back(jb);
     c->pending++;
+    if (h_a && !png && e->ramp && e->cap >= 64 && c->nseg < 2) {
+        // cold-start ramp: mark the copy stream behind the first quarter / half of a full batch's uploads
+        const int sz = (int)c->jobs.size();
+        if (sz == e->cap / 4 || sz == e->cap / 2) {
+            TW_HIP(e, hipEventRecord(c->ev_seg[c->nseg], e->copy_stream));
+            c->seg_at[c->nseg++] = sz;
+        }
+    }
     if (ticket) *ticket = e->next_ticket;
     e->next_ticket++;
     if ((int)c->jobs.size() == e->cap && (r = flush_ctx(e, *c))) {
@@ -2458,6 +2495,7 @@ tw_status tw_engine_create(int device, const tw_params* params, int slots, tw_en
     if (const char* ev = getenv("TW_FI_SKIP")) e->fi_skip = atoi(ev);
 #endif
     if (const char* ev = getenv("TW_LAT_S2_LEVELS")) e->lat_s2_max = atoi(ev);
+    if (const char* ev = getenv("TW_RAMP")) e->ramp = atoi(ev) ? 1 : 0;
     if (const char* ev = getenv("TW_FI_MAXSEG")) e->fi_maxseg = std::min(64, std::max(1, atoi(ev)));
     if (const char* ev = getenv("TW_FI_MINSTEPS")) e->fi_minsteps = std::max(2, atoi(ev));
     // the main stream carries the dependent flow chain: highest priority, so that its small launches are not queued
@@ -2475,6 +2513,8 @@ tw_status tw_engine_create(int device, const tw_params* params, int slots, tw_en
         ok = ok && hipEventCreate(&c.ev_start) == hipSuccess && hipEventCreate(&c.ev_stop) == hipSuccess &&
              hipEventCreateWithFlags(&c.ev_done, hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&c.ev_h2d, hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&c.ev_seg[0], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&c.ev_seg[1], hipEventDisableTiming) == hipSuccess &&
              hipHostMalloc((void**)&c.h_ptrs, sizeof(void*) * 2 * slots, hipHostMallocDefault) == hipSuccess &&
              hipHostMalloc((void**)&c.h_count, sizeof(int) * slots, hipHostMallocDefault) == hipSuccess &&
              hipHostMalloc((void**)&c.h_png, sizeof(PngJob) * 2 * (size_t)slots, hipHostMallocDefault) == hipSuccess &&
@@ -2519,6 +2559,8 @@ void tw_engine_destroy(tw_engine* e)
         if (c.d_png) (void)hipFree(c.d_png);
         if (c.h_png) (void)hipHostFree(c.h_png);
         if (c.ev_h2d) (void)hipEventDestroy(c.ev_h2d);
+        for (hipEvent_t ev : c.ev_seg)
+            if (ev) (void)hipEventDestroy(ev);
         if (c.h_ptrs) (void)hipHostFree((void*)c.h_ptrs);
         if (c.h_count) (void)hipHostFree(c.h_count);
         if (c.h_rec) (void)hipHostFree(c.h_rec);
