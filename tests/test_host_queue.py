@@ -48,7 +48,16 @@ def test_host_layer_under_thread_sanitizer(tmp_path):
     bad[len(bad) // 2] ^= 0x10
     (tmp_path / "bad.png").write_bytes(bytes(bad))
     env = dict(os.environ, TSAN_OPTIONS="halt_on_error=0 exitcode=66")
-    r = subprocess.run([os.path.join(HOST, "build", "tsan_queue"), str(tmp_path)], capture_output=True, text=True, timeout=600, env=env)
+    cmd = [os.path.join(HOST, "build", "tsan_queue"), str(tmp_path)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    if "unexpected memory mapping" in r.stderr:
+        # the sanitizer runtime could not lay out its shadow under this kernel's address-space randomisation (seen on a GPU
+        # box; never in the build container): not a finding about the host layer.  Once more without ASLR, or not at all.
+        if shutil.which("setarch") is None:
+            pytest.skip("ThreadSanitizer cannot map its shadow memory on this kernel")
+        r = subprocess.run(["setarch", os.uname().machine, "-R"] + cmd, capture_output=True, text=True, timeout=600, env=env)
+        if "unexpected memory mapping" in r.stderr or "setarch:" in r.stderr:
+            pytest.skip("ThreadSanitizer cannot map its shadow memory on this kernel")
     assert "ThreadSanitizer" not in r.stderr, r.stderr[-4000:]
     assert r.returncode == 0, r.stdout + r.stderr[-2000:]
     assert "tsan driver: ok" in r.stdout

@@ -2306,16 +2306,17 @@ tw_status submit_common(tw_engine* e, const uint8_t* h_a, const uint8_t* h_b, co
         jb.d_a = (const uint8_t*)d_a;
         jb.d_b = (const uint8_t*)d_b;
     }
-    c->jobs.push_back(jb);
-    c->pending++;
     if (h_a && !png && e->ramp && e->cap >= 64 && c->nseg < 2) {
         // cold-start ramp: mark the copy stream behind the first quarter / half of a full batch's uploads
-        const int sz = (int)c->jobs.size();
+        // (before the job is booked: a failure here leaves the batch as it was)
+        const int sz = (int)c->jobs.size() + 1;
         if (sz == e->cap / 4 || sz == e->cap / 2) {
             TW_HIP(e, hipEventRecord(c->ev_seg[c->nseg], e->copy_stream));
             c->seg_at[c->nseg++] = sz;
         }
     }
+    c->jobs.push_back(jb);
+    c->pending++;
     if (ticket) *ticket = e->next_ticket;
     e->next_ticket++;
     if ((int)c->jobs.size() == e->cap && (r = flush_ctx(e, *c))) {
