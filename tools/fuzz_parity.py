@@ -9,7 +9,10 @@ for single pairs (TW_MFREE=2, no single-pair stream split) so that every level o
 FUZZ_FOCUS=twin (round 5): the single-pair schedule of twin launches — sizes that are multiples of 8 (256..1280 x 200..800),
 polyN 7, winSize 30 / 31, pyrScale 0.5, pyrLevels 3-5, 1-5 iterations, slots = 1.
 FUZZ_FOCUS=big (round 6): single pairs of 1700..2300 x 900..1300 pixels (any remainder), whose level 0 takes the 224 x 8 tiles of
-tw_blur_solve4q — polyN 5 / 7, winSize 30 / 31, pyrScale 0.5 / 0.6, 1-4 levels, 1-3 iterations (a case takes ~3 s of oracle time)."""
+tw_blur_solve4q — polyN 5 / 7, winSize 30 / 31, pyrScale 0.5 / 0.6, 1-4 levels, 1-3 iterations (a case takes ~3 s of oracle time).
+FUZZ_FOCUS=ramp (round 6): the cold-start ramp — a 64-slot engine, 17..64 HOST pairs (two distinct ones, alternating) of 40..420 x 40..700
+pixels submitted into an idle stream, any parameters: every pair's vectors at threshold 0 / 0.5 against the oracle's, and the launch
+counters must show the pieces (more than one polyexp launch per level) whenever more than 16 pairs were submitted."""
 import sys, os, time
 if os.environ.get("FUZZ_FOCUS","")=="mfree":
     os.environ["TW_MFREE"]="2"; os.environ["TW_LATENCY_STREAMS"]="0"
@@ -42,6 +45,29 @@ while n < 3000 and time.time()-t0 < 240:
     b=np.roll(a,int(rng.integers(-3,4)),axis=int(rng.integers(0,2))).copy()
     if kind==2 and h>8 and w>8: b[h//3:h//2,w//4:w//2]=0
     span=int(rng.integers(1,15)); thr=float(rng.choice([0.0,0.5,2.0,5.0]))
+    if focus=="ramp":
+        if h<40 or w<40: continue
+        thr=float(rng.choice([0.0,0.5])); npairs=int(rng.integers(17,65))
+        a2=np.ascontiguousarray(a[::-1]); b2=np.roll(a2,2,axis=1).copy()
+        pairs=[(a,b),(a2,b2)]
+        try:
+            with T.Engine(0,T.default_params(**kw),slots=64) as e:
+                e.launch_counts(reset=True)
+                tk=[e.submit(*pairs[i%2],span,thr) for i in range(npairs)]
+                got=[e.wait(t)["vector"] for t in tk]
+                cnt=e.launch_counts(); lv=e.num_levels(w,h)
+        except T.TwError as ex:
+            if ex.code==T.TW_E_UNSUPPORTED: unsupported+=1; continue
+            raise
+        want=[]
+        for x,y in pairs:
+            wx,wy=O.farneback(x,y,O.default_params(**kw)); want.append(O.span_scan(wx,wy,span,thr))
+        pieces=cnt["tw_polyexp"]//(lv+1) if cnt["tw_polyexp"]%(lv+1)==0 else -1
+        ok=all(g==want[i%2] for i,g in enumerate(got)) and (cnt["tw_polyexp"]==0 or pieces==(3 if npairs>32 else 2))
+        n+=1
+        if not ok:
+            bad+=1; print("MISMATCH",h,w,kw,span,thr,kind,npairs,pieces,dict(cnt), flush=True)
+        continue
     try:
         with T.Engine(0,T.default_params(**kw),slots=1 if focus in ("twin","big") else 2) as e:
             gx,gy,_=e.calculate_internal(a,b)
