@@ -21,8 +21,8 @@ sys.path.insert(0,os.path.join(R,"tidal-wave_amd")); sys.path.insert(0,os.path.j
 import numpy as np, twflow as T, oracle as O
 O.build(); O.lib()
 rng=np.random.default_rng(int(sys.argv[1]) if len(sys.argv)>1 else 2026)
-bad=0; n=0; unsupported=0; t0=time.time()
-while n < 3000 and time.time()-t0 < 240:
+bad=0; n=0; unsupported=0; t0=time.time(); fi_total=[0]
+while n < 3000 and time.time()-t0 < float(os.environ.get("FUZZ_SECONDS","240")):
     h,w=int(rng.integers(1,420)),int(rng.integers(1,700))
     focus=os.environ.get("FUZZ_FOCUS","")  # "win50": the 51-tap window kernels on wide levels (round 3's new default)
     if focus=="win50": h,w=int(rng.integers(1,520)),int(rng.integers(481,1500))
@@ -46,6 +46,10 @@ while n < 3000 and time.time()-t0 < 240:
     if kind==2 and h>8 and w>8: b[h//3:h//2,w//4:w//2]=0
     span=int(rng.integers(1,15)); thr=float(rng.choice([0.0,0.5,2.0,5.0]))
     if focus=="ramp":
+        if os.environ.get("FUZZ_RAMP_MFREE"):  # the pieces through tw_flow_iter: default window, 320..900 columns
+            h,w=int(rng.integers(60,420)),int(rng.integers(320,900))
+            kw.update(winSize=int(rng.choice([30,31])), flags=int(rng.choice([256,260])), polyN=int(rng.choice([5,7])), pyrIterations=int(rng.integers(1,6)))
+            a=rng.integers(0,256,(h,w),dtype=np.uint8); b=np.roll(a,int(rng.integers(-3,4)),axis=int(rng.integers(0,2))).copy()
         if h<40 or w<40: continue
         thr=float(rng.choice([0.0,0.5])); npairs=int(rng.integers(17,65))
         a2=np.ascontiguousarray(a[::-1]); b2=np.roll(a2,2,axis=1).copy()
@@ -55,7 +59,7 @@ while n < 3000 and time.time()-t0 < 240:
                 e.launch_counts(reset=True)
                 tk=[e.submit(*pairs[i%2],span,thr) for i in range(npairs)]
                 got=[e.wait(t)["vector"] for t in tk]
-                cnt=e.launch_counts(); lv=e.num_levels(w,h)
+                cnt=e.launch_counts(); lv=e.num_levels(w,h); fi_total[0]+=cnt["tw_flow_iter"]+cnt["tw_flow_iter_ups"]
         except T.TwError as ex:
             if ex.code==T.TW_E_UNSUPPORTED: unsupported+=1; continue
             raise
@@ -80,4 +84,4 @@ while n < 3000 and time.time()-t0 < 240:
     n+=1
     if not ok:
         bad+=1; print("MISMATCH",h,w,kw,span,thr,kind, float(np.nanmax(np.abs(gx-wx))), flush=True)
-print("fuzz: %d cases, %d mismatches, %d unsupported parameter sets, %.0fs"%(n,bad,unsupported,time.time()-t0))
+print("fuzz: %d cases, %d mismatches, %d unsupported parameter sets, %.0fs"%(n,bad,unsupported,time.time()-t0)+(" (tw_flow_iter launches: %d)"%fi_total[0] if fi_total[0] else ""))
